@@ -1,0 +1,146 @@
+/*
+ * pt_amd.h -- C ABI of the MI355X-native path-tracer hot path (libpt_amd.so).
+ *
+ * Every entry point replaces one interface of the reference (AddisonPrairie/Path-Tracer,
+ * paths relative to /root/reference).  Plain pointers and sizes only; no torch / HIP types.
+ * All functions return 0 on success and a negative pt_status on failure; pt_last_error()
+ * gives the message.  A pt_ctx is bound to ONE GPU and is single-caller (not thread-safe),
+ * like the reference's single JS thread (ray-trace.js:38-39: every dispatch is awaited).
+ *
+ * Ownership: the ctx owns all device memory it allocates; the caller owns every host
+ * pointer it passes in or out.  "dev" pointers are device addresses on the ctx's GPU.
+ */
+#ifndef PT_AMD_H
+#define PT_AMD_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pt_ctx pt_ctx;
+
+enum pt_status {
+    PT_OK = 0, PT_ERR_ARG = -1, PT_ERR_HIP = -2, PT_ERR_STATE = -3, PT_ERR_OOM = -4, PT_ERR_NOGPU = -5
+};
+
+/* ---- records shared with the reference's WGSL structs (bit-exact layouts) ---- */
+/* scene.js:265-274 BVHNode.  child >= 0: inner node index; child < 0: leaf -(child+1).
+ * f_1 / f_2 are excluded from parity (reference: race-dependent arrival counter / 0). */
+typedef struct { float l_min[3]; int32_t l_child; float l_max[3]; int32_t f_1;
+                 float r_min[3]; int32_t r_child; float r_max[3]; int32_t f_2; } pt_bvh_node;   /* 64 B */
+/* scene.js:294-298 Triangle (3 x vec3f padded to 16 B; parse-obj.js:64-68 pads with 3.1415) */
+typedef struct { float v0[3], pad0, v1[3], pad1, v2[3], pad2; } pt_triangle;                     /* 48 B */
+/* scene.js:277-292 Object, as packed by builders.js:28-66 */
+typedef struct { float l2w[3][4]; int32_t bvh_offset, material, f_2, f_3;
+                 float w2l[3][4]; int32_t f_4, f_5, f_6, f_7; } pt_object;                       /* 128 B */
+
+/* One instanceMesh() call after the host computed its matrices (scene.js:523-529,
+ * transform-utils.js:45-59 column-major, rounded to f32 as builders.js:33-58 / :99-107 do). */
+typedef struct {
+    float   l2w[16];        /* localToWorld, column-major */
+    float   w2l[16];        /* worldToLocal, column-major */
+    float   aabb_min[3];    /* world AABB, transform-utils.js:11-43 */
+    float   aabb_max[3];
+    int32_t mesh;           /* handle returned by pt_mesh_upload */
+    int32_t material;       /* material.js:104-111: 0 -> albedo .5, 1 -> albedo .2 */
+} pt_instance;
+
+/* ---- context ---- */
+/* replaces: navigator.gpu.requestAdapter()/requestDevice() (main.js:3-4) + initScene(device) (scene.js:1) */
+int         pt_create(int device_id, pt_ctx** out);
+void        pt_destroy(pt_ctx* ctx);
+const char* pt_last_error(const pt_ctx* ctx);
+/* Optional: run all work on a caller-owned hipStream_t (e.g. torch's current stream). NULL = own stream. */
+int         pt_set_stream(pt_ctx* ctx, void* hip_stream);
+int         pt_sync(pt_ctx* ctx);
+
+/* ---- scene (scripts/scene) ---- */
+/* replaces: scene.registerMesh({file}) (scene.js:518-521) after parseObj (builders.js:155):
+ * tris12 = parseObj().triangleArray (12 f32 per triangle), bounds = {min xyz, max xyz} over all
+ * `v` lines (parse-obj.js:33-38).  Returns the mesh handle (>= 0) or a negative status.
+ * The BLAS is built on the device on first use by pt_scene_build and cached (scene.js:25-27). */
+int pt_mesh_upload(pt_ctx* ctx, const float* tris12, int64_t n_tris, const float bounds[6]);
+/* replaces: await scene.build() (scene.js:15-146): per-mesh LBVH (builders.js:153-214), packMeshes
+ * (pack-t-mesh.js), TLAS (builders.js:97-151), packObjects (builders.js:25-95). */
+int pt_scene_build(pt_ctx* ctx, const pt_instance* instances, int n_instances);
+
+typedef struct { int64_t n_tris; int32_t n_objects; int32_t n_meshes_used; } pt_scene_info;
+int pt_scene_get_info(pt_ctx* ctx, pt_scene_info* out);
+/* Parity read-backs of the four scene buffers of the reference's bind group (scene.js:68-73)
+ * and of the sort permutations (builders.js:26 reads the TLAS one back, too). n = element count. */
+int pt_get_blas_nodes(pt_ctx* ctx, pt_bvh_node* out, int64_t n);
+int pt_get_blas_tris(pt_ctx* ctx, pt_triangle* out, int64_t n);
+int pt_get_tlas_nodes(pt_ctx* ctx, pt_bvh_node* out, int64_t n);
+int pt_get_objects(pt_ctx* ctx, pt_object* out, int64_t n);
+int pt_get_tlas_perm(pt_ctx* ctx, int32_t* out, int64_t n);
+int pt_get_mesh_perm(pt_ctx* ctx, int mesh, int32_t* out, int64_t n);
+
+/* Test hook over the extend kernel (ray-trace.js:53-69 + scene.js:313-475 intersect_bvh) for
+ * caller-supplied rays.  o3/d3: n x 3 floats (host).  Outputs (host, any may be NULL):
+ * hit_obj (TLAS-sorted object index or -1), hit_tri (packed triangle index or -1), hit_dist,
+ * counts4 = per-ray {n_inner, n_leaf, n_enter, n_leave} visit counts. */
+int pt_trace_rays(pt_ctx* ctx, const float* o3, const float* d3, int64_t n,
+                  int32_t* hit_obj, int32_t* hit_tri, float* hit_dist, int32_t* counts4);
+
+/* ---- render (scripts/render) ---- */
+typedef struct {
+    int32_t width, height;           /* params.image (path-tracer.js:57-58) */
+    float   cam_pos[3];              /* params.camera.position (path-tracer.js:64-66) */
+    float   cam_look_at[3];          /* params.camera.lookAt   (path-tracer.js:68-70) */
+    float   fov_deg;                 /* params.camera.fov      (path-tracer.js:62) */
+    int32_t spp;                     /* params.settings.samples (path-tracer.js:19) */
+    int32_t num_paths;               /* NUM_PATHS (path-tracer.js:4); 0 -> 1,000,000 */
+    /* multi-GPU spp split (no reference counterpart; all 0 / -1 reproduces the reference) */
+    int64_t slot_base;               /* global slot index of local slot 0 (RNG stream id, logic.js:77) */
+    int64_t ticket_begin, ticket_end;/* this GPU's pixel-ticket range; ticket_end < 0 -> all tickets */
+    void*   image_dev;               /* optional caller-owned W*H*4 f32 device buffer (zeroed by init) */
+} pt_render_params;
+
+/* replaces: initPathTracer({device, scene, image, camera, settings}) (path-tracer.js:1-47,207-329) */
+int pt_render_init(pt_ctx* ctx, const pt_render_params* params);
+
+typedef struct {
+    int64_t n_camera;     /* stage_2_queue_size[0] after logic (path-tracer.js:174) */
+    int64_t n_material;   /* stage_2_queue_size[1] */
+    int64_t n_rays;       /* stage_3_queue_size[0]: rays traced this step */
+    int64_t step_index;
+} pt_step_stats;
+/* replaces: await pt.step() (path-tracer.js:49-123): logic -> camera -> material -> ray-trace.
+ * stats may be NULL (then no host sync happens). */
+int pt_render_step(pt_ctx* ctx, pt_step_stats* stats);
+
+typedef struct {
+    int64_t steps;              /* step() calls issued */
+    int64_t total_rays;         /* sum of stage-3 queue sizes */
+    int64_t total_samples;      /* finished camera samples (= sum of image .w) */
+    int64_t stack_overflows;    /* rays that hit the traversal guards (0 on sane scenes) */
+    double  extend_ms;          /* sum of extend-kernel durations (HIP events), if timed */
+    int64_t extend_launches;
+    int64_t traversal_bytes;    /* algorithmic bytes if counted, else 0 */
+} pt_run_stats;
+enum { PT_RUN_TIME_EXTEND = 1, PT_RUN_COUNT_BYTES = 2 };
+/* The reference's requestAnimationFrame loop (main.js:61-72) made headless: step until both
+ * stage-2 queues are empty (or max_steps).  flags: PT_RUN_* . */
+int pt_render_run(pt_ctx* ctx, int64_t max_steps, int flags, pt_run_stats* out);
+
+/* replaces: pt.getImageBuffer() (path-tracer.js:125-127) + a read-back the reference lacks.
+ * rgba: W*H*4 floats (rgb = sum of radiance, a = finished samples; logic.js:146-149). */
+int pt_image_read(pt_ctx* ctx, float* rgba, int64_t n_floats);
+int pt_image_dev_ptr(pt_ctx* ctx, void** dev_ptr);
+/* Parity read-back of one PathState member (path-tracer.js:131-160) by name; vec3f/vec4f members
+ * come back as 4 floats per slot.  "pixel_counter" returns one int64. */
+int pt_path_state_read(pt_ctx* ctx, const char* field, void* out, size_t bytes);
+/* stage-2 queues of the last step: which = 0 camera_queue, 1 material_queue. *n_io in: capacity, out: count */
+int pt_queue_read(pt_ctx* ctx, int which, int32_t* out, int64_t* n_io);
+
+/* ---- display (scripts/display) ---- */
+/* replaces: initDisplay().draw() fragment shader (display.js:98-113) + canvas unorm8 store.
+ * image_dev NULL -> the ctx's image.  rgba8: W*H*4 bytes (host), row 0 = top. */
+int pt_tonemap_rgba8(pt_ctx* ctx, const void* image_dev, int32_t width, int32_t height, uint8_t* rgba8);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

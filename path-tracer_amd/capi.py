@@ -1,0 +1,95 @@
+"""ctypes binding of libpt_amd.so (the C ABI declared in include/pt_amd.h).
+
+This module is plumbing only: it loads the in-tree shared library and declares argument types.
+There is no fallback: if the HIP library is missing or no GPU is visible the calls raise."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpt_amd.so")
+
+PT_RUN_TIME_EXTEND = 1
+PT_RUN_COUNT_BYTES = 2
+
+
+class PtInstance(C.Structure):
+    _fields_ = [("l2w", C.c_float * 16), ("w2l", C.c_float * 16), ("aabb_min", C.c_float * 3),
+                ("aabb_max", C.c_float * 3), ("mesh", C.c_int32), ("material", C.c_int32)]
+
+
+class PtSceneInfo(C.Structure):
+    _fields_ = [("n_tris", C.c_int64), ("n_objects", C.c_int32), ("n_meshes_used", C.c_int32)]
+
+
+class PtRenderParams(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("cam_pos", C.c_float * 3),
+                ("cam_look_at", C.c_float * 3), ("fov_deg", C.c_float), ("spp", C.c_int32),
+                ("num_paths", C.c_int32), ("slot_base", C.c_int64), ("ticket_begin", C.c_int64),
+                ("ticket_end", C.c_int64), ("image_dev", C.c_void_p)]
+
+
+class PtStepStats(C.Structure):
+    _fields_ = [("n_camera", C.c_int64), ("n_material", C.c_int64), ("n_rays", C.c_int64), ("step_index", C.c_int64)]
+
+
+class PtRunStats(C.Structure):
+    _fields_ = [("steps", C.c_int64), ("total_rays", C.c_int64), ("total_samples", C.c_int64),
+                ("stack_overflows", C.c_int64), ("extend_ms", C.c_double), ("extend_launches", C.c_int64),
+                ("traversal_bytes", C.c_int64)]
+
+
+# name -> (restype, argtypes); every symbol include/pt_amd.h declares
+SIGNATURES = {
+    "pt_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "pt_destroy": (None, [C.c_void_p]),
+    "pt_last_error": (C.c_char_p, [C.c_void_p]),
+    "pt_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pt_sync": (C.c_int, [C.c_void_p]),
+    "pt_mesh_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "pt_scene_build": (C.c_int, [C.c_void_p, C.POINTER(PtInstance), C.c_int]),
+    "pt_scene_get_info": (C.c_int, [C.c_void_p, C.POINTER(PtSceneInfo)]),
+    "pt_get_blas_nodes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "pt_get_blas_tris": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "pt_get_tlas_nodes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "pt_get_objects": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "pt_get_tlas_perm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "pt_get_mesh_perm": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
+    "pt_trace_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pt_render_init": (C.c_int, [C.c_void_p, C.POINTER(PtRenderParams)]),
+    "pt_render_step": (C.c_int, [C.c_void_p, C.POINTER(PtStepStats)]),
+    "pt_render_run": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.POINTER(PtRunStats)]),
+    "pt_image_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "pt_image_dev_ptr": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "pt_path_state_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),
+    "pt_queue_read": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int64)]),
+    "pt_tonemap_rgba8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libpt_amd.so (built by `make -C path-tracer_amd/csrc` / __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C path-tracer_amd/csrc` "
+                               "(there is no CPU fallback for the hot path)")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+class PtError(RuntimeError):
+    pass
+
+
+def check(lib, ctx, rc, what):
+    if rc < 0:
+        msg = lib.pt_last_error(ctx)
+        raise PtError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+    return rc

@@ -1,0 +1,480 @@
+// pt_api.hip -- host side of libpt_amd.so: context, device memory, launch sequencing, C ABI.
+// Declarations and the reference interface each entry point replaces: include/pt_amd.h.
+#include "pt_amd.h"
+#include "pt_internal.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static_assert(sizeof(pt_bvh_node) == 64 && sizeof(pt_triangle) == 48 && sizeof(pt_object) == 128, "record layouts");
+static_assert(sizeof(pt_instance) == 160, "pt_instance is 40 words (k_pack_objects)");
+
+namespace {
+
+thread_local std::string g_err;   // errors raised before a ctx exists
+
+struct Mesh {
+    int64_t n = 0; float bounds[6] = {0, 0, 0, 0, 0, 0};
+    float4* d_tris_in = nullptr;      // upload order (parse-obj.js order)
+    float4* d_nodes = nullptr;        // per-mesh BLAS, child pointers relative to the mesh
+    float4* d_tris_sorted = nullptr;  // Morton order
+    int32_t* d_perm = nullptr;        // sorted position -> upload position
+    bool built = false, used = false; int64_t tri_offset = 0;
+};
+
+}  // namespace
+
+struct pt_ctx {
+    int device = 0; hipStream_t stream = nullptr; bool own_stream = false; std::string err;
+    std::vector<Mesh> meshes;
+    // scene
+    bool scene_built = false; int64_t n_tris = 0; int n_objects = 0; int n_meshes_used = 0;
+    float4 *d_blas_nodes = nullptr, *d_blas_tris = nullptr, *d_tlas_nodes = nullptr, *d_objects = nullptr;
+    int32_t* d_tlas_perm = nullptr;
+    // render
+    bool render_ready = false; RenderConst rc{}; PathState ps{};
+    float* d_image = nullptr; bool own_image = false; uint8_t* d_code = nullptr;
+    int4 *d_blk_counts = nullptr, *d_blk_offsets = nullptr; int32_t *d_cam_q = nullptr, *d_mat_q = nullptr, *d_spill = nullptr;
+    StepHeader* d_hdr = nullptr; StepHeader* h_hdr = nullptr; int nblocks = 0; int64_t step = 0;
+    std::vector<void*> render_allocs; std::vector<hipEvent_t> events;
+};
+
+namespace {
+
+int fail(pt_ctx* c, int code, const std::string& msg) { if (c) c->err = msg; else g_err = msg; return code; }
+
+#define HIPOK(c, expr)                                                                                          \
+    do {                                                                                                        \
+        hipError_t e_ = (expr);                                                                                 \
+        if (e_ != hipSuccess)                                                                                   \
+            return fail(c, e_ == hipErrorOutOfMemory ? PT_ERR_OOM : PT_ERR_HIP,                                 \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                                     \
+    } while (0)
+
+template <typename T> int dalloc(pt_ctx* c, T** p, size_t count, bool zero) {
+    *p = nullptr;
+    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    HIPOK(c, hipMalloc((void**)p, bytes));
+    if (zero) HIPOK(c, hipMemsetAsync(*p, 0, bytes, c->stream));
+    return PT_OK;
+}
+void dfree(void* p) { if (p) (void)hipFree(p); }
+
+SceneView scene_view(const pt_ctx* c) { SceneView v; v.tlas = c->d_tlas_nodes; v.objects = c->d_objects; v.blas = c->d_blas_nodes; v.tris = c->d_blas_tris; return v; }
+
+// builders.js:174-192: sort -> radix tree -> up pass.  aabb: 2 quads per primitive; keys are consumed.
+int build_bvh(pt_ctx* c, const float4* d_aabb, uint32_t* d_keys, int64_t n, int32_t* d_perm_out, float4* d_nodes_out) {
+    uint32_t* d_keys_sorted = nullptr; int32_t *d_iota = nullptr, *d_parents = nullptr; void* d_tmp = nullptr; size_t tmp_bytes = 0;
+    int rc = PT_OK;
+    if ((rc = dalloc(c, &d_keys_sorted, (size_t)n, false))) return rc;
+    if ((rc = dalloc(c, &d_iota, (size_t)n, false))) return rc;
+    if ((rc = dalloc(c, &d_parents, (size_t)(2 * n), true))) return rc;
+    HIPOK(c, hipMemsetAsync(d_nodes_out, 0, (size_t)n * 64, c->stream));   // WebGPU zero-fills BVH_BUFFER; f_1 is the arrival counter
+    ptk_iota(d_iota, n, c->stream);
+    HIPOK(c, pt_sort_pairs_u32(nullptr, &tmp_bytes, d_keys, d_keys_sorted, d_iota, d_perm_out, (size_t)n, c->stream));
+    HIPOK(c, hipMalloc(&d_tmp, std::max<size_t>(tmp_bytes, 16)));
+    HIPOK(c, pt_sort_pairs_u32(d_tmp, &tmp_bytes, d_keys, d_keys_sorted, d_iota, d_perm_out, (size_t)n, c->stream));
+    ptk_radix_tree(d_keys_sorted, n, d_parents, c->stream);
+    ptk_up_pass(d_perm_out, d_aabb, d_parents, n, d_nodes_out, c->stream);
+    HIPOK(c, hipGetLastError());
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    dfree(d_keys_sorted); dfree(d_iota); dfree(d_parents); dfree(d_tmp);
+    return PT_OK;
+}
+
+// builders.js:153-214 buildMeshBVH
+int build_mesh(pt_ctx* c, Mesh& m) {
+    float4* d_aabb = nullptr; uint32_t* d_keys = nullptr; int rc;
+    if ((rc = dalloc(c, &d_aabb, (size_t)m.n * 2, false))) return rc;
+    if ((rc = dalloc(c, &d_keys, (size_t)m.n, false))) return rc;
+    if ((rc = dalloc(c, &m.d_nodes, (size_t)m.n * 4, false))) return rc;
+    if ((rc = dalloc(c, &m.d_tris_sorted, (size_t)m.n * 3, false))) return rc;
+    if ((rc = dalloc(c, &m.d_perm, (size_t)m.n, false))) return rc;
+    ptk_tri_aabb_morton(m.d_tris_in, m.n, m.bounds, d_aabb, d_keys, c->stream);
+    if ((rc = build_bvh(c, d_aabb, d_keys, m.n, m.d_perm, m.d_nodes))) return rc;
+    ptk_rearrange(m.d_tris_in, m.d_perm, m.n, m.d_tris_sorted, c->stream);
+    HIPOK(c, hipGetLastError());
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    dfree(d_aabb); dfree(d_keys);
+    m.built = true;
+    return PT_OK;
+}
+
+void free_scene(pt_ctx* c) {
+    dfree(c->d_blas_nodes); dfree(c->d_blas_tris); dfree(c->d_tlas_nodes); dfree(c->d_objects); dfree(c->d_tlas_perm);
+    c->d_blas_nodes = c->d_blas_tris = c->d_tlas_nodes = c->d_objects = nullptr; c->d_tlas_perm = nullptr; c->scene_built = false;
+}
+void free_render(pt_ctx* c) {
+    for (void* p : c->render_allocs) dfree(p);
+    c->render_allocs.clear();
+    if (c->h_hdr) { (void)hipHostFree(c->h_hdr); c->h_hdr = nullptr; }
+    for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+    c->events.clear();
+    c->render_ready = false; c->d_image = nullptr;
+}
+
+template <typename T> int ralloc(pt_ctx* c, T** p, size_t count) {
+    int rc = dalloc(c, p, count, true);
+    if (rc == PT_OK) c->render_allocs.push_back(*p);
+    return rc;
+}
+
+int read_back(pt_ctx* c, void* dst, const void* src, size_t bytes) {
+    HIPOK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+void enqueue_step(pt_ctx* c, int count_visits, hipEvent_t ev0, hipEvent_t ev1) {
+    SceneView sv = scene_view(c);
+    ptk_logic(c->ps, c->rc, c->step == 0 ? 1 : 0, c->d_image, c->d_code, c->d_blk_counts, c->stream);
+    ptk_scan(c->d_blk_counts, c->d_blk_offsets, c->nblocks, c->d_hdr, c->stream);
+    ptk_compact(c->ps, c->rc, c->d_code, c->d_blk_offsets, c->d_hdr, c->d_cam_q, c->d_mat_q, c->stream);
+    ptk_generate(c->ps, c->rc, c->d_hdr, c->d_cam_q, c->stream);
+    ptk_shade(c->ps, c->rc, sv, c->d_hdr, c->d_mat_q, c->stream);
+    if (ev0) (void)hipEventRecord(ev0, c->stream);
+    ptk_extend_queue(c->ps, c->rc, sv, c->d_hdr, c->d_cam_q, c->d_mat_q, c->d_spill, count_visits, c->stream);
+    if (ev1) (void)hipEventRecord(ev1, c->stream);
+    c->step++;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pt_create(int device_id, pt_ctx** out) {
+    if (!out) return fail(nullptr, PT_ERR_ARG, "pt_create: out is null");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(nullptr, PT_ERR_NOGPU, "pt_create: no HIP device visible");
+    if (device_id < 0 || device_id >= n) return fail(nullptr, PT_ERR_ARG, "pt_create: device_id out of range");
+    pt_ctx* c = new pt_ctx();
+    c->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
+        delete c; return fail(nullptr, PT_ERR_HIP, "pt_create: hipSetDevice/hipStreamCreate failed");
+    }
+    c->own_stream = true;
+    *out = c;
+    return PT_OK;
+}
+
+void pt_destroy(pt_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_render(c); free_scene(c);
+    for (Mesh& m : c->meshes) { dfree(m.d_tris_in); dfree(m.d_nodes); dfree(m.d_tris_sorted); dfree(m.d_perm); }
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* pt_last_error(const pt_ctx* c) { return c ? c->err.c_str() : g_err.c_str(); }
+
+int pt_set_stream(pt_ctx* c, void* hip_stream) {
+    if (!c) return PT_ERR_ARG;
+    HIPOK(c, hipSetDevice(c->device));
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    if (c->own_stream) { (void)hipStreamDestroy(c->stream); c->own_stream = false; }
+    if (hip_stream) c->stream = (hipStream_t)hip_stream;
+    else { HIPOK(c, hipStreamCreate(&c->stream)); c->own_stream = true; }
+    return PT_OK;
+}
+
+int pt_sync(pt_ctx* c) {
+    if (!c) return PT_ERR_ARG;
+    HIPOK(c, hipSetDevice(c->device));
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+// ------------------------------------------------------------------------------------------ scene
+int pt_mesh_upload(pt_ctx* c, const float* tris12, int64_t n_tris, const float bounds[6]) {
+    if (!c || !tris12 || !bounds) return fail(c, PT_ERR_ARG, "pt_mesh_upload: null argument");
+    if (n_tris < 1 || n_tris > (1ll << 30)) return fail(c, PT_ERR_ARG, "pt_mesh_upload: n_tris must be in [1, 2^30]");
+    HIPOK(c, hipSetDevice(c->device));
+    Mesh m; m.n = n_tris; memcpy(m.bounds, bounds, 24);
+    int rc = dalloc(c, &m.d_tris_in, (size_t)n_tris * 3, false);
+    if (rc) return rc;
+    HIPOK(c, hipMemcpyAsync(m.d_tris_in, tris12, (size_t)n_tris * 48, hipMemcpyHostToDevice, c->stream));
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    c->meshes.push_back(m);
+    return (int)c->meshes.size() - 1;
+}
+
+int pt_scene_build(pt_ctx* c, const pt_instance* inst, int n_inst) {
+    if (!c || !inst) return fail(c, PT_ERR_ARG, "pt_scene_build: null argument");
+    if (n_inst < 1) return fail(c, PT_ERR_ARG, "pt_scene_build: the scene needs at least one instance");
+    HIPOK(c, hipSetDevice(c->device));
+    for (int i = 0; i < n_inst; i++)
+        if (inst[i].mesh < 0 || inst[i].mesh >= (int)c->meshes.size())   // scene.js:524-526
+            return fail(c, PT_ERR_ARG, "pt_scene_build: mesh with ID " + std::to_string(inst[i].mesh) + " does not exist");
+    free_render(c); free_scene(c);
+    // scene.js:17-29: used meshes in ascending id order, running triangle offset, BLAS cached per mesh
+    for (Mesh& m : c->meshes) m.used = false;
+    for (int i = 0; i < n_inst; i++) c->meshes[inst[i].mesh].used = true;
+    int64_t off = 0; int used = 0; int rc;
+    std::vector<int32_t> mesh_off(c->meshes.size(), 0);
+    for (size_t k = 0; k < c->meshes.size(); k++) {
+        Mesh& m = c->meshes[k];
+        if (!m.used) continue;
+        m.tri_offset = off; mesh_off[k] = (int32_t)off; used++;
+        if (!m.built && (rc = build_mesh(c, m))) return rc;
+        off += m.n;
+    }
+    if (off > (1ll << 30)) return fail(c, PT_ERR_ARG, "pt_scene_build: more than 2^30 packed triangles");
+    c->n_tris = off; c->n_objects = n_inst; c->n_meshes_used = used;
+    // pack-t-mesh.js: concatenate + rebase
+    if ((rc = dalloc(c, &c->d_blas_nodes, (size_t)off * 4, false))) return rc;
+    if ((rc = dalloc(c, &c->d_blas_tris, (size_t)off * 3, false))) return rc;
+    for (Mesh& m : c->meshes)
+        if (m.used) ptk_pack_mesh(m.d_nodes, m.d_tris_sorted, m.n, (int32_t)m.tri_offset, c->d_blas_nodes, c->d_blas_tris, c->stream);
+    // scene.js:42-61 scene bounds; builders.js:97-151 buildTLAS
+    float sb[6] = {1e30f, 1e30f, 1e30f, -1e30f, -1e30f, -1e30f};
+    std::vector<float> aabbs((size_t)n_inst * 8, 0.0f);
+    for (int i = 0; i < n_inst; i++)
+        for (int k = 0; k < 3; k++) {
+            aabbs[8 * i + k] = inst[i].aabb_min[k]; aabbs[8 * i + 4 + k] = inst[i].aabb_max[k];
+            sb[k] = fminf(sb[k], inst[i].aabb_min[k]); sb[3 + k] = fmaxf(sb[3 + k], inst[i].aabb_max[k]);
+        }
+    float4* d_aabb = nullptr; uint32_t* d_keys = nullptr; void* d_inst = nullptr; int32_t* d_mesh_off = nullptr;
+    if ((rc = dalloc(c, &d_aabb, (size_t)n_inst * 2, false))) return rc;
+    if ((rc = dalloc(c, &d_keys, (size_t)n_inst, false))) return rc;
+    if ((rc = dalloc(c, &c->d_tlas_nodes, (size_t)n_inst * 4, false))) return rc;
+    if ((rc = dalloc(c, &c->d_tlas_perm, (size_t)n_inst, false))) return rc;
+    if ((rc = dalloc(c, &c->d_objects, (size_t)n_inst * 8, false))) return rc;
+    if ((rc = dalloc(c, (char**)&d_inst, (size_t)n_inst * sizeof(pt_instance), false))) return rc;
+    if ((rc = dalloc(c, &d_mesh_off, mesh_off.size(), false))) return rc;
+    HIPOK(c, hipMemcpyAsync(d_aabb, aabbs.data(), aabbs.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPOK(c, hipMemcpyAsync(d_inst, inst, (size_t)n_inst * sizeof(pt_instance), hipMemcpyHostToDevice, c->stream));
+    HIPOK(c, hipMemcpyAsync(d_mesh_off, mesh_off.data(), mesh_off.size() * 4, hipMemcpyHostToDevice, c->stream));
+    ptk_obj_morton(d_aabb, n_inst, sb, d_keys, c->stream);
+    if ((rc = build_bvh(c, d_aabb, d_keys, n_inst, c->d_tlas_perm, c->d_tlas_nodes))) return rc;
+    ptk_pack_objects(d_inst, c->d_tlas_perm, d_mesh_off, n_inst, c->d_objects, c->stream);
+    HIPOK(c, hipGetLastError());
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    dfree(d_aabb); dfree(d_keys); dfree(d_inst); dfree(d_mesh_off);
+    c->scene_built = true;
+    return PT_OK;
+}
+
+int pt_scene_get_info(pt_ctx* c, pt_scene_info* out) {
+    if (!c || !out) return fail(c, PT_ERR_ARG, "pt_scene_get_info: null argument");
+    if (!c->scene_built) return fail(c, PT_ERR_STATE, "scene has not been built yet");   // scene.js:149
+    out->n_tris = c->n_tris; out->n_objects = c->n_objects; out->n_meshes_used = c->n_meshes_used;
+    return PT_OK;
+}
+
+#define SCENE_GETTER(name, T, ptr, count)                                                                      \
+    int name(pt_ctx* c, T* out, int64_t n) {                                                                    \
+        if (!c || !out) return fail(c, PT_ERR_ARG, #name ": null argument");                                    \
+        if (!c->scene_built) return fail(c, PT_ERR_STATE, "scene has not been built yet");                     \
+        if (n != (int64_t)(count)) return fail(c, PT_ERR_ARG, #name ": n does not match the scene");            \
+        HIPOK(c, hipSetDevice(c->device));                                                                      \
+        return read_back(c, out, ptr, (size_t)n * sizeof(T));                                                   \
+    }
+SCENE_GETTER(pt_get_blas_nodes, pt_bvh_node, c->d_blas_nodes, c->n_tris)
+SCENE_GETTER(pt_get_blas_tris, pt_triangle, c->d_blas_tris, c->n_tris)
+SCENE_GETTER(pt_get_tlas_nodes, pt_bvh_node, c->d_tlas_nodes, c->n_objects)
+SCENE_GETTER(pt_get_objects, pt_object, c->d_objects, c->n_objects)
+SCENE_GETTER(pt_get_tlas_perm, int32_t, c->d_tlas_perm, c->n_objects)
+
+int pt_get_mesh_perm(pt_ctx* c, int mesh, int32_t* out, int64_t n) {
+    if (!c || !out) return fail(c, PT_ERR_ARG, "pt_get_mesh_perm: null argument");
+    if (mesh < 0 || mesh >= (int)c->meshes.size() || !c->meshes[mesh].built) return fail(c, PT_ERR_STATE, "pt_get_mesh_perm: mesh not built");
+    if (n != c->meshes[mesh].n) return fail(c, PT_ERR_ARG, "pt_get_mesh_perm: n does not match the mesh");
+    HIPOK(c, hipSetDevice(c->device));
+    return read_back(c, out, c->meshes[mesh].d_perm, (size_t)n * 4);
+}
+
+int pt_trace_rays(pt_ctx* c, const float* o3, const float* d3, int64_t n, int32_t* hit_obj, int32_t* hit_tri, float* hit_dist,
+                  int32_t* counts4) {
+    if (!c || !o3 || !d3 || n < 0) return fail(c, PT_ERR_ARG, "pt_trace_rays: bad argument");
+    if (!c->scene_built) return fail(c, PT_ERR_STATE, "scene has not been built yet");
+    HIPOK(c, hipSetDevice(c->device));
+    const int64_t CH = 1 << 20;
+    int64_t cap = std::min<int64_t>(std::max<int64_t>(n, 1), CH);
+    float4 *d_o = nullptr, *d_d = nullptr; int32_t *d_ho = nullptr, *d_ht = nullptr, *d_spill = nullptr; float* d_hd = nullptr; int4* d_cnt = nullptr;
+    StepHeader* d_hdr = nullptr; int rc;
+    if ((rc = dalloc(c, &d_o, (size_t)cap, false)) || (rc = dalloc(c, &d_d, (size_t)cap, false)) || (rc = dalloc(c, &d_ho, (size_t)cap, false)) ||
+        (rc = dalloc(c, &d_ht, (size_t)cap, false)) || (rc = dalloc(c, &d_hd, (size_t)cap, false)) || (rc = dalloc(c, &d_cnt, (size_t)cap, false)) ||
+        (rc = dalloc(c, &d_spill, ptk_spill_ints(cap), false)) || (rc = dalloc(c, &d_hdr, 1, true)))
+        return rc;
+    std::vector<float> stage((size_t)cap * 4);
+    SceneView sv = scene_view(c);
+    for (int64_t base = 0; base < n; base += CH) {
+        int64_t m = std::min(CH, n - base);
+        for (int pass = 0; pass < 2; pass++) {
+            const float* src = (pass ? d3 : o3) + 3 * base;
+            for (int64_t i = 0; i < m; i++) { stage[4 * i] = src[3 * i]; stage[4 * i + 1] = src[3 * i + 1]; stage[4 * i + 2] = src[3 * i + 2]; stage[4 * i + 3] = 0.0f; }
+            HIPOK(c, hipMemcpyAsync(pass ? d_d : d_o, stage.data(), (size_t)m * 16, hipMemcpyHostToDevice, c->stream));
+            HIPOK(c, hipStreamSynchronize(c->stream));
+        }
+        ptk_extend_direct(sv, d_o, d_d, (int)m, d_ho, d_ht, d_hd, counts4 ? d_cnt : nullptr, d_spill, d_hdr, c->stream);
+        HIPOK(c, hipGetLastError());
+        if (hit_obj) HIPOK(c, hipMemcpyAsync(hit_obj + base, d_ho, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
+        if (hit_tri) HIPOK(c, hipMemcpyAsync(hit_tri + base, d_ht, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
+        if (hit_dist) HIPOK(c, hipMemcpyAsync(hit_dist + base, d_hd, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
+        if (counts4) HIPOK(c, hipMemcpyAsync(counts4 + 4 * base, d_cnt, (size_t)m * 16, hipMemcpyDeviceToHost, c->stream));
+        HIPOK(c, hipStreamSynchronize(c->stream));
+    }
+    dfree(d_o); dfree(d_d); dfree(d_ho); dfree(d_ht); dfree(d_hd); dfree(d_cnt); dfree(d_spill); dfree(d_hdr);
+    return PT_OK;
+}
+
+// ----------------------------------------------------------------------------------------- render
+int pt_render_init(pt_ctx* c, const pt_render_params* p) {
+    if (!c || !p) return fail(c, PT_ERR_ARG, "pt_render_init: null argument");
+    if (!c->scene_built) return fail(c, PT_ERR_STATE, "scene has not been built yet");   // scene.js:149 via path-tracer.js:209
+    if (p->width < 1 || p->height < 1 || (int64_t)p->width * p->height > (1ll << 29) || p->spp < 1)
+        return fail(c, PT_ERR_ARG, "pt_render_init: bad image size or spp");
+    int64_t np = p->num_paths > 0 ? p->num_paths : 1000000;   // path-tracer.js:4
+    if (np > (1ll << 28)) return fail(c, PT_ERR_ARG, "pt_render_init: num_paths too large");
+    HIPOK(c, hipSetDevice(c->device));
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    free_render(c);
+    RenderConst& rc = c->rc;
+    rc.width = p->width; rc.height = p->height; rc.num_paths = (int32_t)np; rc.spp = p->spp; rc.fov_deg = p->fov_deg;
+    for (int k = 0; k < 3; k++) { rc.cam_pos[k] = p->cam_pos[k]; rc.cam_look_at[k] = p->cam_look_at[k]; }
+    int64_t total = ((int64_t)p->width * p->height * p->spp + PT_SAMPLES_PER_TICKET - 1) / PT_SAMPLES_PER_TICKET;   // logic.js:177
+    rc.slot_base = p->slot_base;
+    rc.ticket_limit = p->ticket_end >= 0 ? p->ticket_end : total;
+    int64_t ticket_begin = p->ticket_end >= 0 ? p->ticket_begin : 0;
+    int r; size_t n = (size_t)np;
+    PathState& ps = c->ps;   // zero-filled like a new GPUBuffer (path-tracer.js:271-275)
+    if ((r = ralloc(c, &ps.pixel_index, n)) || (r = ralloc(c, &ps.num_bounces, n)) || (r = ralloc(c, &ps.random_seed, n)) ||
+        (r = ralloc(c, &ps.path_throughput, n)) || (r = ralloc(c, &ps.material_throughput_pdf, n)) || (r = ralloc(c, &ps.path_o, n)) ||
+        (r = ralloc(c, &ps.path_d, n)) || (r = ralloc(c, &ps.hit_obj, n)) || (r = ralloc(c, &ps.hit_tri, n)) || (r = ralloc(c, &ps.flags, n)) ||
+        (r = ralloc(c, &ps.samples_in_pixel, n)))
+        return r;
+    c->nblocks = (int)((np + PT_BLOCK - 1) / PT_BLOCK);
+    if ((r = ralloc(c, &c->d_code, n)) || (r = ralloc(c, &c->d_blk_counts, (size_t)c->nblocks)) || (r = ralloc(c, &c->d_blk_offsets, (size_t)c->nblocks)) ||
+        (r = ralloc(c, &c->d_cam_q, n)) || (r = ralloc(c, &c->d_mat_q, n)) || (r = ralloc(c, &c->d_spill, ptk_spill_ints(np))) ||
+        (r = ralloc(c, &c->d_hdr, 1)))
+        return r;
+    size_t img_floats = (size_t)p->width * p->height * 4;
+    if (p->image_dev) { c->d_image = (float*)p->image_dev; c->own_image = false; HIPOK(c, hipMemsetAsync(c->d_image, 0, img_floats * 4, c->stream)); }
+    else { if ((r = ralloc(c, &c->d_image, img_floats))) return r; c->own_image = true; }
+    HIPOK(c, hipHostMalloc((void**)&c->h_hdr, sizeof(StepHeader), hipHostMallocDefault));
+    StepHeader h; memset(&h, 0, sizeof h);
+    h.first_empty_step = -1; h.pixel_counter = ticket_begin;
+    *c->h_hdr = h;
+    HIPOK(c, hipMemcpyAsync(c->d_hdr, c->h_hdr, sizeof h, hipMemcpyHostToDevice, c->stream));
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    c->step = 0; c->render_ready = true;
+    return PT_OK;
+}
+
+int pt_render_step(pt_ctx* c, pt_step_stats* stats) {
+    if (!c) return PT_ERR_ARG;
+    if (!c->render_ready) return fail(c, PT_ERR_STATE, "pt_render_step: pt_render_init has not been called");
+    HIPOK(c, hipSetDevice(c->device));
+    enqueue_step(c, 0, nullptr, nullptr);
+    HIPOK(c, hipGetLastError());
+    if (stats) {
+        int r = read_back(c, c->h_hdr, c->d_hdr, sizeof(StepHeader));
+        if (r) return r;
+        stats->n_camera = c->h_hdr->n_camera; stats->n_material = c->h_hdr->n_material; stats->n_rays = c->h_hdr->n_rays;
+        stats->step_index = c->step - 1;
+    }
+    return PT_OK;
+}
+
+int pt_render_run(pt_ctx* c, int64_t max_steps, int flags, pt_run_stats* out) {
+    if (!c) return PT_ERR_ARG;
+    if (!c->render_ready) return fail(c, PT_ERR_STATE, "pt_render_run: pt_render_init has not been called");
+    HIPOK(c, hipSetDevice(c->device));
+    const int POLL = 8;   // steps between looks at the queue sizes (the reference never looks: main.js:61-72)
+    bool timed = (flags & PT_RUN_TIME_EXTEND) != 0; int count = (flags & PT_RUN_COUNT_BYTES) ? 1 : 0;
+    if (timed && c->events.empty()) {
+        c->events.resize(2 * POLL);
+        for (hipEvent_t& e : c->events) HIPOK(c, hipEventCreate(&e));
+    }
+    double extend_ms = 0.0; int64_t launches = 0, issued = 0;
+    if (max_steps <= 0) max_steps = INT64_MAX;
+    for (;;) {
+        int k = 0;
+        for (; k < POLL && issued < max_steps; k++, issued++)
+            enqueue_step(c, count, timed ? c->events[2 * k] : nullptr, timed ? c->events[2 * k + 1] : nullptr);
+        HIPOK(c, hipGetLastError());
+        int r = read_back(c, c->h_hdr, c->d_hdr, sizeof(StepHeader));
+        if (r) return r;
+        if (timed)
+            for (int j = 0; j < k; j++) { float ms = 0; HIPOK(c, hipEventElapsedTime(&ms, c->events[2 * j], c->events[2 * j + 1])); extend_ms += ms; launches++; }
+        if (c->h_hdr->first_empty_step >= 0 || issued >= max_steps) break;
+    }
+    if (out) {
+        const StepHeader& h = *c->h_hdr;
+        out->steps = h.first_empty_step >= 0 ? h.first_empty_step + 1 : h.step_index;
+        out->total_rays = h.total_rays; out->total_samples = h.total_samples; out->stack_overflows = (int64_t)h.overflow;
+        out->extend_ms = extend_ms; out->extend_launches = launches;
+        out->traversal_bytes = count ? (int64_t)(44 * h.total_rays + 64 * h.visits[0] + 48 * h.visits[1] + 128 * (h.visits[2] + h.visits[3])) : 0;
+    }
+    return PT_OK;
+}
+
+int pt_image_read(pt_ctx* c, float* rgba, int64_t n_floats) {
+    if (!c || !rgba) return fail(c, PT_ERR_ARG, "pt_image_read: null argument");
+    if (!c->render_ready) return fail(c, PT_ERR_STATE, "pt_image_read: pt_render_init has not been called");
+    if (n_floats != (int64_t)c->rc.width * c->rc.height * 4) return fail(c, PT_ERR_ARG, "pt_image_read: size mismatch");
+    HIPOK(c, hipSetDevice(c->device));
+    return read_back(c, rgba, c->d_image, (size_t)n_floats * 4);
+}
+
+int pt_image_dev_ptr(pt_ctx* c, void** dev_ptr) {
+    if (!c || !dev_ptr) return fail(c, PT_ERR_ARG, "pt_image_dev_ptr: null argument");
+    if (!c->render_ready) return fail(c, PT_ERR_STATE, "pt_image_dev_ptr: pt_render_init has not been called");
+    *dev_ptr = c->d_image;
+    return PT_OK;
+}
+
+int pt_path_state_read(pt_ctx* c, const char* field, void* out, size_t bytes) {
+    if (!c || !field || !out) return fail(c, PT_ERR_ARG, "pt_path_state_read: null argument");
+    if (!c->render_ready) return fail(c, PT_ERR_STATE, "pt_path_state_read: pt_render_init has not been called");
+    HIPOK(c, hipSetDevice(c->device));
+    const PathState& ps = c->ps; size_t n = (size_t)c->rc.num_paths; const void* src = nullptr; size_t need = 0;
+    struct { const char* name; const void* p; size_t elem; } tab[] = {
+        {"pixel_index", ps.pixel_index, 4}, {"num_bounces", ps.num_bounces, 4}, {"random_seed", ps.random_seed, 4},
+        {"path_throughput", ps.path_throughput, 16}, {"material_throughput_pdf", ps.material_throughput_pdf, 16},
+        {"path_o", ps.path_o, 16}, {"path_d", ps.path_d, 16}, {"hit_obj", ps.hit_obj, 4}, {"hit_tri", ps.hit_tri, 4},
+        {"flags", ps.flags, 4}, {"samples_in_pixel", ps.samples_in_pixel, 4}};
+    for (auto& t : tab) if (!strcmp(field, t.name)) { src = t.p; need = n * t.elem; }
+    if (!strcmp(field, "pixel_counter")) { src = &c->d_hdr->pixel_counter; need = 8; }
+    if (!src) return fail(c, PT_ERR_ARG, std::string("pt_path_state_read: unknown field ") + field);
+    if (bytes != need) return fail(c, PT_ERR_ARG, "pt_path_state_read: size mismatch");
+    return read_back(c, out, src, need);
+}
+
+int pt_queue_read(pt_ctx* c, int which, int32_t* out, int64_t* n_io) {
+    if (!c || !out || !n_io || which < 0 || which > 1) return fail(c, PT_ERR_ARG, "pt_queue_read: bad argument");
+    if (!c->render_ready) return fail(c, PT_ERR_STATE, "pt_queue_read: pt_render_init has not been called");
+    HIPOK(c, hipSetDevice(c->device));
+    int r = read_back(c, c->h_hdr, c->d_hdr, sizeof(StepHeader));
+    if (r) return r;
+    int64_t cnt = which == 0 ? c->h_hdr->n_camera : c->h_hdr->n_material;
+    if (cnt > *n_io) return fail(c, PT_ERR_ARG, "pt_queue_read: buffer too small");
+    *n_io = cnt;
+    return cnt ? read_back(c, out, which == 0 ? c->d_cam_q : c->d_mat_q, (size_t)cnt * 4) : PT_OK;
+}
+
+// ---------------------------------------------------------------------------------------- display
+int pt_tonemap_rgba8(pt_ctx* c, const void* image_dev, int32_t width, int32_t height, uint8_t* rgba8) {
+    if (!c || !rgba8) return fail(c, PT_ERR_ARG, "pt_tonemap_rgba8: null argument");
+    HIPOK(c, hipSetDevice(c->device));
+    if (!image_dev) {
+        if (!c->render_ready) return fail(c, PT_ERR_STATE, "pt_tonemap_rgba8: no image");
+        image_dev = c->d_image; width = c->rc.width; height = c->rc.height;
+    }
+    if (width < 1 || height < 1) return fail(c, PT_ERR_ARG, "pt_tonemap_rgba8: bad size");
+    int64_t n = (int64_t)width * height; uint32_t* d_out = nullptr; int r;
+    if ((r = dalloc(c, &d_out, (size_t)n, false))) return r;
+    ptk_tonemap((const float4*)image_dev, n, d_out, c->stream);
+    HIPOK(c, hipGetLastError());
+    r = read_back(c, rgba8, d_out, (size_t)n * 4);
+    dfree(d_out);
+    return r;
+}
+
+}  // extern "C"

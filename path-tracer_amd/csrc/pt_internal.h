@@ -1,0 +1,87 @@
+// pt_internal.h -- shared between the kernel translation units and the C-ABI host code.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define PT_BLOCK 256                 // threads per workgroup: 4 wave64
+#define PT_STACK_SIZE 64             // traversal stack entries per ray (reference: 32, scene.js:305)
+#define PT_LDS_STACK 24              // of which the first PT_LDS_STACK live in LDS, the rest in an HBM spill
+#define PT_MAX_ITERS (1 << 20)       // traversal loop guard (degenerate N=1 trees can self-loop)
+#define PT_SAMPLES_PER_TICKET 8      // logic.js:6 SAMPLES_PER_PIXEL_PER_PATH
+
+// ---- device views ---------------------------------------------------------------------------
+// The four scene buffers of the reference's bind group (scene.js:68-73), each addressed as
+// 16-byte quads: a 64-B node = 4 quads, a 48-B triangle = 3, a 128-B object = 8.
+struct SceneView {
+    const float4* tlas;      // pt_bvh_node[n_objects]
+    const float4* objects;   // pt_object[n_objects]
+    const float4* blas;      // pt_bvh_node[n_tris]
+    const float4* tris;      // pt_triangle[n_tris]
+};
+
+// PathState (path-tracer.js:131-160) as separate device arrays; vec3f members keep the
+// reference's 16-byte stride.
+struct PathState {
+    int32_t*  pixel_index;
+    int32_t*  num_bounces;
+    float*    random_seed;
+    float4*   path_throughput;
+    float4*   material_throughput_pdf;
+    float4*   path_o;
+    float4*   path_d;
+    int32_t*  hit_obj;
+    int32_t*  hit_tri;
+    uint32_t* flags;
+    int32_t*  samples_in_pixel;
+};
+
+// Device-resident step header: queue sizes (QueuesStage*.stage_N_queue_size, path-tracer.js:173-204),
+// the pixel ticket counter (PathState.pixel_counter) and run totals.
+struct StepHeader {
+    int32_t  n_camera, n_material, n_rays, first_empty_step;   // first_empty_step: -1 until both queues are empty
+    int64_t  pixel_counter;      // next ticket to hand out
+    int64_t  ticket_base;        // pixel_counter at the start of the current step
+    int64_t  total_rays;
+    int64_t  total_samples;
+    unsigned long long overflow; // rays stopped by the stack / iteration guards
+    unsigned long long visits[4];// n_inner, n_leaf, n_enter, n_leave (counting variant only)
+    int32_t  step_index, pad;
+};
+
+struct RenderConst {
+    int32_t width, height, num_paths, spp;
+    float   cam_pos[3], cam_look_at[3], fov_deg;
+    int64_t slot_base, ticket_limit;
+};
+
+// ---- launchers (pt_kernels_build.hip) ---------------------------------------------------------
+void ptk_tri_aabb_morton(const float4* tris, int64_t n, const float bounds[6], float4* aabb, uint32_t* keys, hipStream_t s);
+void ptk_obj_morton(const float4* aabb, int64_t n, const float bounds[6], uint32_t* keys, hipStream_t s);
+void ptk_iota(int32_t* idx, int64_t n, hipStream_t s);
+void ptk_radix_tree(const uint32_t* sorted_keys, int64_t n, int32_t* parents /* 2n, zeroed */, hipStream_t s);
+void ptk_up_pass(const int32_t* idx, const float4* aabb, const int32_t* parents, int64_t n, float4* nodes /* zeroed */, hipStream_t s);
+void ptk_rearrange(const float4* tris_in, const int32_t* idx, int64_t n, float4* tris_out, hipStream_t s);
+void ptk_pack_mesh(const float4* src_nodes, const float4* src_tris, int64_t n, int32_t offset, float4* dst_nodes, float4* dst_tris, hipStream_t s);
+void ptk_pack_objects(const void* instances /* pt_instance[n] */, const int32_t* tlas_perm, const int32_t* mesh_tri_offset,
+                      int n, float4* objects, hipStream_t s);
+hipError_t pt_sort_pairs_u32(void* tmp, size_t* tmp_bytes, const uint32_t* kin, uint32_t* kout,
+                             const int32_t* vin, int32_t* vout, size_t n, hipStream_t s);
+
+// ---- launchers (pt_kernels_render.hip) --------------------------------------------------------
+void ptk_logic(const PathState& ps, const RenderConst& rc, int first_sample, float* image, uint8_t* code,
+               int4* blk_counts, hipStream_t s);
+void ptk_scan(const int4* blk_counts, int4* blk_offsets, int nblocks, StepHeader* hdr, hipStream_t s);
+void ptk_compact(const PathState& ps, const RenderConst& rc, const uint8_t* code, const int4* blk_offsets,
+                 const StepHeader* hdr, int32_t* cam_q, int32_t* mat_q, hipStream_t s);
+void ptk_generate(const PathState& ps, const RenderConst& rc, const StepHeader* hdr, const int32_t* cam_q, hipStream_t s);
+void ptk_shade(const PathState& ps, const RenderConst& rc, const SceneView& sc, const StepHeader* hdr,
+               const int32_t* mat_q, hipStream_t s);
+// Extend over the step's ray queue (camera ++ material).  count != 0 selects the visit-counting variant.
+void ptk_extend_queue(const PathState& ps, const RenderConst& rc, const SceneView& sc, StepHeader* hdr,
+                      const int32_t* cam_q, const int32_t* mat_q, int32_t* spill, int count, hipStream_t s);
+// Extend over n caller rays (o4/d4: float4 per ray).  counts4 (int4 per ray) may be null.
+void ptk_extend_direct(const SceneView& sc, const float4* o4, const float4* d4, int n, int32_t* hit_obj,
+                       int32_t* hit_tri, float* hit_dist, int4* counts4, int32_t* spill, StepHeader* hdr, hipStream_t s);
+void ptk_tonemap(const float4* image, int64_t n_pixels, uint32_t* rgba8, hipStream_t s);
+size_t ptk_spill_ints(int64_t n_rays);   // ints needed in the spill buffer for a launch over n_rays

@@ -1,0 +1,201 @@
+// pt_kernels_build.hip -- LBVH construction on gfx950.
+//
+// Pipeline per mesh (and once more over object boxes for the TLAS):
+//   boxes + 30-bit Morton keys -> stable key/index sort (rocPRIM, pt_sort.hip) -> Karras radix
+//   tree (parent links carry the child's side) -> bottom-up refit -> gather triangles -> pack.
+// All of it is HBM-streaming integer/f32 work; no LDS tiling or MFMA applies.  The refit is the
+// only inter-workgroup hand-off and uses agent-scope release/acquire around one arrival counter.
+#include "pt_internal.h"
+#include "pt_math.cuh"
+
+static inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + PT_BLOCK - 1) / PT_BLOCK)); }
+
+struct Bounds { float mn[3], mx[3]; };
+
+// aabb-z-idx.js:202-209 split_3 / :197-199 morton_code
+__device__ __forceinline__ uint32_t split_3(uint32_t x) {
+    x = (x | (x << 16)) & 0x030000FFu;
+    x = (x | (x << 8)) & 0x0300F00Fu;
+    x = (x | (x << 4)) & 0x030C30C3u;
+    x = (x | (x << 2)) & 0x09249249u;
+    return x;
+}
+// aabb-z-idx.js:191-194: centroid relative to the bounds, * 1023.99, truncated
+__device__ __forceinline__ uint32_t morton_of_box(f3 mn, f3 mx, const Bounds& b) {
+    f3 cen = (mx + mn) * 0.5f;
+    f3 num = cen - F3(b.mn[0], b.mn[1], b.mn[2]);
+    f3 den = F3(b.mx[0], b.mx[1], b.mx[2]) - F3(b.mn[0], b.mn[1], b.mn[2]);
+    f3 rel = F3(num.x / den.x, num.y / den.y, num.z / den.z);
+    uint32_t ux = f32_to_u32(rel.x * 1023.99f), uy = f32_to_u32(rel.y * 1023.99f), uz = f32_to_u32(rel.z * 1023.99f);
+    return split_3(ux) | (split_3(uy) << 1) | (split_3(uz) << 2);
+}
+
+// aabb-z-idx.js:176-195
+__global__ __launch_bounds__(PT_BLOCK) void k_tri_aabb_morton(const float4* __restrict__ tris, int64_t n, Bounds b,
+                                                              float4* __restrict__ aabb, uint32_t* __restrict__ keys) {
+    int64_t i = (int64_t)blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    f3 v0 = F3(tris[3 * i]), v1 = F3(tris[3 * i + 1]), v2 = F3(tris[3 * i + 2]);
+    f3 mn = min3(v0, min3(v1, v2)), mx = max3(v0, max3(v1, v2));
+    aabb[2 * i]     = make_float4(mn.x, mn.y, mn.z, 0.0f);
+    aabb[2 * i + 1] = make_float4(mx.x, mx.y, mx.z, 0.0f);
+    keys[i]         = morton_of_box(mn, mx, b);
+}
+// aabb2z-idx.js:157-170
+__global__ __launch_bounds__(PT_BLOCK) void k_obj_morton(const float4* __restrict__ aabb, int64_t n, Bounds b,
+                                                         uint32_t* __restrict__ keys) {
+    int64_t i = (int64_t)blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    keys[i] = morton_of_box(F3(aabb[2 * i]), F3(aabb[2 * i + 1]), b);
+}
+// radix-sort.js:526-534 init_idx
+__global__ __launch_bounds__(PT_BLOCK) void k_iota(int32_t* __restrict__ idx, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (i < n) idx[i] = (int32_t)i;
+}
+
+// radix-tree.js:160-185: common-prefix length, equal keys fall back to the index bits
+__device__ __forceinline__ int del_(const uint32_t* __restrict__ keys, int n, int i1, int i2) {
+    if (i2 < 0 || i2 >= n) return -1;
+    uint32_t x = keys[i1] ^ keys[i2];
+    if (x) return __builtin_clz(x);
+    uint32_t y = (uint32_t)i1 ^ (uint32_t)i2;
+    return y ? 32 + __builtin_clz(y) : 31;
+}
+// radix-tree.js:136-157 + :188-238.  One thread per inner node i.  Instead of a bare parent index the
+// link stores (parent << 1 | side) so that the refit can place each child in its Karras slot
+// (left = lower key range) without depending on arrival order.
+__global__ __launch_bounds__(PT_BLOCK) void k_radix_tree(const uint32_t* __restrict__ keys, int n, int32_t* __restrict__ parents) {
+    int i = blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (i >= n - 1) return;
+    int a = del_(keys, n, i, i + 1) - del_(keys, n, i, i - 1);
+    int d = (a > 0) - (a < 0);
+    int del_min = del_(keys, n, i, i - d);
+    int l_max = 2;
+    // i + l_max*d stays inside int: n <= 2^30 is checked by the host
+    while (del_(keys, n, i, i + l_max * d) > del_min) l_max *= 2;
+    int l = 0;
+    for (int t = l_max / 2; t > 0; t /= 2)
+        if (del_(keys, n, i, i + (l + t) * d) > del_min) l += t;
+    int j = i + l * d;
+    int del_node = del_(keys, n, i, j);
+    // largest s in [0, l) with del(i, i + s*d) > del_node: Karras' t = ceil(l/2), ceil(l/4), ..., 1
+    int s = 0, t = l;
+    do {
+        t = (t + 1) / 2;
+        if (del_(keys, n, i, i + (s + t) * d) > del_node) s += t;
+    } while (t > 1);
+    int gamma = i + s * d + min(d, 0);
+    int lo = min(i, j), hi = max(i, j);
+    int left_slot  = (lo == gamma) ? n + gamma : gamma;           // leaf links live at parents[n + leaf]
+    int right_slot = (hi == gamma + 1) ? n + gamma + 1 : gamma + 1;
+    parents[left_slot]  = (i << 1);
+    parents[right_slot] = (i << 1) | 1;
+}
+
+// bvh-up-pass.js:199-280.  One thread per leaf climbs the tree; the second child to arrive at a node
+// merges both boxes and continues.  Differences from the reference kernel, none visible in the output
+// of its canonical (serial) execution: the child's slot is its Karras side, not its arrival rank; the
+// first arriver publishes its slot with an agent-scope release before the counter, the second acquires
+// after it, so there is no "is the other half still zero" spin (bvh-up-pass.js:266-268).
+__global__ __launch_bounds__(PT_BLOCK) void k_up_pass(const int32_t* __restrict__ idx, const float4* __restrict__ aabb,
+                                                      const int32_t* __restrict__ parents, int n, float4* nodes) {
+    int t = blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (t >= n) return;
+    int src = idx[t];
+    f3  mn = F3(aabb[2 * (int64_t)src]), mx = F3(aabb[2 * (int64_t)src + 1]);
+    // :209-210 exact zeros are nudged because 0 doubles as "not written yet" in the reference
+    mn.x -= (mn.x == 0.0f ? 1.0f : 0.0f) * 1e-8f; mn.y -= (mn.y == 0.0f ? 1.0f : 0.0f) * 1e-8f;
+    mn.z -= (mn.z == 0.0f ? 1.0f : 0.0f) * 1e-8f;
+    mx.x += (mx.x == 0.0f ? 1.0f : 0.0f) * 1e-8f; mx.y += (mx.y == 0.0f ? 1.0f : 0.0f) * 1e-8f;
+    mx.z += (mx.z == 0.0f ? 1.0f : 0.0f) * 1e-8f;
+    int w_idx = -(t + 1);
+    int link  = parents[(int64_t)n + t];
+    for (int level = 0; level < 64; level++) {   // tree depth <= 62 (32 key bits + 30 index bits)
+        int    p = link >> 1, side = link & 1;
+        float* nd = (float*)(nodes + 4 * (int64_t)p);
+        float* slot = nd + 8 * side;
+        slot[0] = mn.x; slot[1] = mn.y; slot[2] = mn.z; ((int*)slot)[3] = w_idx;
+        slot[4] = mx.x; slot[5] = mx.y; slot[6] = mx.z;
+        __threadfence();                                   // release my slot (agent scope)
+        int arrived = atomicAdd((int*)nd + 7, 1);          // f_1 doubles as the arrival counter (:230)
+        if (arrived == 0) return;                          // first arrival stops (:242)
+        __threadfence();                                   // acquire the sibling's slot
+        const float* sib = nd + 8 * (side ^ 1);
+        f3 smn = F3(sib[0], sib[1], sib[2]), smx = F3(sib[4], sib[5], sib[6]);
+        mn = min3(mn, smn); mx = max3(mx, smx);            // :270-271
+        if (p == 0) return;                                // merged into the root (:218 w_idx == 0)
+        w_idx = p;
+        link  = parents[p];
+    }
+}
+
+// rearrange.js:162-169
+__global__ __launch_bounds__(PT_BLOCK) void k_rearrange(const float4* __restrict__ in, const int32_t* __restrict__ idx, int64_t n,
+                                                        float4* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    int64_t s = idx[i];
+    out[3 * i] = in[3 * s]; out[3 * i + 1] = in[3 * s + 1]; out[3 * i + 2] = in[3 * s + 2];
+}
+
+// pack-t-mesh.js:218-245: copy one triangle and one node per thread, rebasing child pointers
+__global__ __launch_bounds__(PT_BLOCK) void k_pack_mesh(const float4* __restrict__ src_nodes, const float4* __restrict__ src_tris,
+                                                        int64_t n, int32_t offset, float4* __restrict__ dst_nodes,
+                                                        float4* __restrict__ dst_tris) {
+    int64_t i = (int64_t)blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    int64_t o = (int64_t)offset + i;
+    dst_tris[3 * o] = src_tris[3 * i]; dst_tris[3 * o + 1] = src_tris[3 * i + 1]; dst_tris[3 * o + 2] = src_tris[3 * i + 2];
+    float4 q0 = src_nodes[4 * i], q1 = src_nodes[4 * i + 1], q2 = src_nodes[4 * i + 2], q3 = src_nodes[4 * i + 3];
+    int lc = __float_as_int(q0.w), rc = __float_as_int(q2.w);
+    lc = lc < 0 ? lc - offset : lc + offset;
+    rc = rc < 0 ? rc - offset : rc + offset;
+    q0.w = __int_as_float(lc); q2.w = __int_as_float(rc);
+    dst_nodes[4 * o] = q0; dst_nodes[4 * o + 1] = q1; dst_nodes[4 * o + 2] = q2; dst_nodes[4 * o + 3] = q3;
+}
+
+// builders.js:25-67 packObjects, on the device (the reference reads the TLAS permutation back
+// and packs on the host).  instances: pt_instance[n] = {l2w[16], w2l[16], aabb[6], mesh, material}, 40 words.
+__global__ __launch_bounds__(PT_BLOCK) void k_pack_objects(const float* __restrict__ inst, const int32_t* __restrict__ perm,
+                                                           const int32_t* __restrict__ mesh_tri_offset, int n, float4* __restrict__ objects) {
+    int i = blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float* in = inst + 40 * (int64_t)perm[i];
+    const float* l2w = in; const float* w2l = in + 16;
+    int mesh = ((const int*)in)[38], material = ((const int*)in)[39];
+    float4* ob = objects + 8 * (int64_t)i;
+    for (int r = 0; r < 3; r++) {   // row r of a column-major 4x4: m[r], m[4+r], m[8+r], m[12+r] (builders.js:33-58)
+        ob[r]     = make_float4(l2w[r], l2w[4 + r], l2w[8 + r], l2w[12 + r]);
+        ob[4 + r] = make_float4(w2l[r], w2l[4 + r], w2l[8 + r], w2l[12 + r]);
+    }
+    ob[3] = make_float4(__int_as_float(mesh_tri_offset[mesh]), __int_as_float(material), 0.0f, 0.0f);   // builders.js:64-65
+    ob[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+// ---- launchers -------------------------------------------------------------------------------
+static Bounds mk_bounds(const float b[6]) { Bounds r; for (int i = 0; i < 3; i++) { r.mn[i] = b[i]; r.mx[i] = b[3 + i]; } return r; }
+
+void ptk_tri_aabb_morton(const float4* tris, int64_t n, const float bounds[6], float4* aabb, uint32_t* keys, hipStream_t s) {
+    hipLaunchKernelGGL(k_tri_aabb_morton, grid_for(n), dim3(PT_BLOCK), 0, s, tris, n, mk_bounds(bounds), aabb, keys);
+}
+void ptk_obj_morton(const float4* aabb, int64_t n, const float bounds[6], uint32_t* keys, hipStream_t s) {
+    hipLaunchKernelGGL(k_obj_morton, grid_for(n), dim3(PT_BLOCK), 0, s, aabb, n, mk_bounds(bounds), keys);
+}
+void ptk_iota(int32_t* idx, int64_t n, hipStream_t s) { hipLaunchKernelGGL(k_iota, grid_for(n), dim3(PT_BLOCK), 0, s, idx, n); }
+void ptk_radix_tree(const uint32_t* keys, int64_t n, int32_t* parents, hipStream_t s) {
+    if (n < 2) return;
+    hipLaunchKernelGGL(k_radix_tree, grid_for(n - 1), dim3(PT_BLOCK), 0, s, keys, (int)n, parents);
+}
+void ptk_up_pass(const int32_t* idx, const float4* aabb, const int32_t* parents, int64_t n, float4* nodes, hipStream_t s) {
+    hipLaunchKernelGGL(k_up_pass, grid_for(n), dim3(PT_BLOCK), 0, s, idx, aabb, parents, (int)n, nodes);
+}
+void ptk_rearrange(const float4* in, const int32_t* idx, int64_t n, float4* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_rearrange, grid_for(n), dim3(PT_BLOCK), 0, s, in, idx, n, out);
+}
+void ptk_pack_mesh(const float4* src_nodes, const float4* src_tris, int64_t n, int32_t offset, float4* dst_nodes, float4* dst_tris, hipStream_t s) {
+    hipLaunchKernelGGL(k_pack_mesh, grid_for(n), dim3(PT_BLOCK), 0, s, src_nodes, src_tris, n, offset, dst_nodes, dst_tris);
+}
+void ptk_pack_objects(const void* instances, const int32_t* perm, const int32_t* mesh_tri_offset, int n, float4* objects, hipStream_t s) {
+    hipLaunchKernelGGL(k_pack_objects, grid_for(n), dim3(PT_BLOCK), 0, s, (const float*)instances, perm, mesh_tri_offset, n, objects);
+}

@@ -1,0 +1,443 @@
+// pt_kernels_render.hip -- the wavefront integrator on gfx950.
+//
+// One step() = logic -> scan -> compact -> generate -> shade -> extend, all on one stream, no host
+// round trip in between (the reference awaits the queue after each of its four dispatches,
+// path-tracer.js:86-107).  Queue appends are order-preserving: wave64 ballots give each lane its
+// rank, one scan over per-workgroup counts gives each workgroup its base, so every queue is in
+// ascending path-slot order and pixel tickets are handed out in slot order (the reference's
+// canonical serial order; its own order is a race, logic.js:158,168,205,213).
+// Because every camera-queue and every material-queue entry produces exactly one ray, the ray-trace
+// queue (QueuesStage3.ray_trace_queue) is the concatenation camera ++ material and is never stored.
+#include "pt_internal.h"
+#include "pt_math.cuh"
+
+#define ALBEDO0_POW 0.217637640824031f   // pow(0.5, 2.2): material.js:107 through :72
+#define ALBEDO1_POW 0.0289911870530680f  // pow(0.2, 2.2): material.js:110 through :72
+
+static inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + PT_BLOCK - 1) / PT_BLOCK)); }
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int rank_below(unsigned long long mask) {   // set bits below my lane
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+}
+
+// ============================================================================================
+// logic (logic.js:62-152): per-slot state machine, image accumulation, decisions
+// ============================================================================================
+// code bits: 1 = camera queue, 2 = material queue, 4 = wants a pixel ticket.
+// blk_counts[b] = {#camera, #material, #tickets, #finished samples} of workgroup b.
+__global__ __launch_bounds__(PT_BLOCK) void k_logic(PathState ps, RenderConst rc, int first_sample, float* __restrict__ image,
+                                                    uint8_t* __restrict__ code_out, int4* __restrict__ blk_counts) {
+    __shared__ int4 s_wave[PT_BLOCK / 64];
+    int i = blockIdx.x * PT_BLOCK + threadIdx.x;
+    unsigned code = 0; bool finished = false;
+    if (i < rc.num_paths && (ps.flags[i] & (1u << 31)) == 0u) {
+        if (first_sample) {
+            uint32_t gi = (uint32_t)(rc.slot_base + i);
+            ps.random_seed[i] = (float)base_hash(gi, gi + 1u) * 2.3283064365386962890625e-10f + 0.008f;   // logic.js:77
+            ps.path_throughput[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+            code = 1u | 4u;
+        } else {
+            f3  tp = F3(ps.path_throughput[i]);
+            int nb = ps.num_bounces[i] + 1;
+            bool b_hit = ps.hit_obj[i] >= 0;
+            uint32_t flags = ps.flags[i];
+            f3 contrib = F3(0.0f, 0.0f, 0.0f);
+            if (flags & 1u) {                                                   // logic.js:94-109
+                tp = tp * F3(ps.material_throughput_pdf[i]);
+                if (nb > 3) {
+                    float seed = ps.random_seed[i];
+                    float2 r2 = rand2(seed);
+                    ps.random_seed[i] = seed + 2.0f;
+                    float q = fmin_(fmax_(0.1f, 1.0f - tp.y), 0.7f);
+                    if (r2.x < q) tp = F3(0.0f, 0.0f, 0.0f); else tp = tp / (1.0f - q);
+                }
+            }
+            if (nb > 20) tp = F3(0.0f, 0.0f, 0.0f);                              // logic.js:111-113
+            if (!b_hit) { contrib = F3(0.0f + 2.0f * tp.x, 0.0f + 2.0f * tp.y, 0.0f + 2.0f * tp.z); tp = F3(0.0f, 0.0f, 0.0f); }
+            if (tp.x == 0.0f && tp.y == 0.0f && tp.z == 0.0f) {                  // logic.js:121-133
+                finished = true; code |= 1u; nb = 0; tp = F3(1.0f, 1.0f, 1.0f);
+                int sip = ps.samples_in_pixel[i];
+                if (sip >= PT_SAMPLES_PER_TICKET - 1) code |= 4u; else ps.samples_in_pixel[i] = sip + 1;
+            } else { code |= 2u; nb += 1; }
+            ps.path_throughput[i] = make_float4(tp.x, tp.y, tp.z, 0.0f);
+            ps.num_bounces[i] = nb;
+            ps.flags[i] = 0u;
+            if (finished || contrib.x != 0.0f || contrib.y != 0.0f || contrib.z != 0.0f) {   // logic.js:145-150
+                float* px = image + 4 * (int64_t)ps.pixel_index[i];
+                unsafeAtomicAdd(px + 0, contrib.x); unsafeAtomicAdd(px + 1, contrib.y);
+                unsafeAtomicAdd(px + 2, contrib.z); unsafeAtomicAdd(px + 3, finished ? 1.0f : 0.0f);
+            }
+        }
+    }
+    if (i < rc.num_paths) code_out[i] = (uint8_t)code;
+    unsigned long long b_cam = __ballot(code & 1u), b_mat = __ballot(code & 2u), b_tix = __ballot(code & 4u), b_fin = __ballot(finished);
+    if (lane_id() == 0)
+        s_wave[threadIdx.x >> 6] = make_int4(__popcll(b_cam), __popcll(b_mat), __popcll(b_tix), __popcll(b_fin));
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int4 t = s_wave[0];
+        for (int w = 1; w < PT_BLOCK / 64; w++) { t.x += s_wave[w].x; t.y += s_wave[w].y; t.z += s_wave[w].z; t.w += s_wave[w].w; }
+        blk_counts[blockIdx.x] = t;
+    }
+}
+
+// ============================================================================================
+// scan: exclusive prefix over the per-workgroup counts; publishes queue sizes and ticket base
+// ============================================================================================
+__global__ __launch_bounds__(1024) void k_scan(const int4* __restrict__ blk_counts, int4* __restrict__ blk_offsets, int nblocks,
+                                               StepHeader* hdr) {
+    __shared__ int4 s_wave[16];
+    __shared__ int4 s_carry;
+    int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_carry = make_int4(0, 0, 0, 0);
+    __syncthreads();
+    for (int base = 0; base < nblocks; base += 1024) {
+        int  b = base + tid;
+        int4 v = b < nblocks ? blk_counts[b] : make_int4(0, 0, 0, 0);
+        int4 inc = v;
+        for (int off = 1; off < 64; off <<= 1) {   // inclusive scan inside the wave
+            int x = __shfl_up(inc.x, off), y = __shfl_up(inc.y, off), z = __shfl_up(inc.z, off), w = __shfl_up(inc.w, off);
+            if (lane >= off) { inc.x += x; inc.y += y; inc.z += z; inc.w += w; }
+        }
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        int4 wbase = make_int4(0, 0, 0, 0);
+        for (int w = 0; w < wave; w++) { wbase.x += s_wave[w].x; wbase.y += s_wave[w].y; wbase.z += s_wave[w].z; wbase.w += s_wave[w].w; }
+        int4 carry = s_carry;
+        if (b < nblocks)
+            blk_offsets[b] = make_int4(carry.x + wbase.x + inc.x - v.x, carry.y + wbase.y + inc.y - v.y,
+                                       carry.z + wbase.z + inc.z - v.z, 0);
+        __syncthreads();
+        if (tid == 1023) s_carry = make_int4(carry.x + wbase.x + inc.x, carry.y + wbase.y + inc.y, carry.z + wbase.z + inc.z, carry.w + wbase.w + inc.w);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int4 tot = s_carry;
+        hdr->n_camera = tot.x; hdr->n_material = tot.y; hdr->n_rays = tot.x + tot.y;
+        hdr->ticket_base = hdr->pixel_counter;
+        hdr->pixel_counter += tot.z;
+        hdr->total_rays += (int64_t)tot.x + tot.y;
+        hdr->total_samples += tot.w;
+        if (tot.x + tot.y == 0 && hdr->first_empty_step < 0) hdr->first_empty_step = hdr->step_index;
+        hdr->step_index += 1;
+    }
+}
+
+// ============================================================================================
+// compact: stable scatter into the camera / material queues + pixel tickets (logic.js:155-219)
+// ============================================================================================
+__global__ __launch_bounds__(PT_BLOCK) void k_compact(PathState ps, RenderConst rc, const uint8_t* __restrict__ code_in,
+                                                      const int4* __restrict__ blk_offsets, const StepHeader* __restrict__ hdr,
+                                                      int32_t* __restrict__ cam_q, int32_t* __restrict__ mat_q) {
+    __shared__ int4 s_wave[PT_BLOCK / 64];
+    int i = blockIdx.x * PT_BLOCK + threadIdx.x;
+    unsigned code = i < rc.num_paths ? code_in[i] : 0u;
+    unsigned long long b_cam = __ballot(code & 1u), b_mat = __ballot(code & 2u), b_tix = __ballot(code & 4u);
+    int wave = threadIdx.x >> 6;
+    if (lane_id() == 0) s_wave[wave] = make_int4(__popcll(b_cam), __popcll(b_mat), __popcll(b_tix), 0);
+    __syncthreads();
+    int4 off = blk_offsets[blockIdx.x];
+    for (int w = 0; w < wave; w++) { off.x += s_wave[w].x; off.y += s_wave[w].y; off.z += s_wave[w].z; }
+    if (code & 1u) cam_q[off.x + rank_below(b_cam)] = i;
+    if (code & 2u) mat_q[off.y + rank_below(b_mat)] = i;
+    if (code & 4u) {
+        int64_t ticket = hdr->ticket_base + off.z + rank_below(b_tix);
+        if (ticket >= rc.ticket_limit) ps.flags[i] |= (1u << 31);                  // logic.js:177-179
+        else {                                                                      // logic.js:181-182
+            ps.pixel_index[i] = (int32_t)(ticket % ((int64_t)rc.width * rc.height));
+            ps.samples_in_pixel[i] = 0;
+        }
+    }
+}
+
+// ============================================================================================
+// generate (camera.js:60-118)
+// ============================================================================================
+__global__ __launch_bounds__(PT_BLOCK) void k_generate(PathState ps, RenderConst rc, const StepHeader* __restrict__ hdr,
+                                                       const int32_t* __restrict__ cam_q) {
+    int q = blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (q >= hdr->n_camera) return;
+    int path = cam_q[q];
+    int px = ps.pixel_index[path];
+    float seed = ps.random_seed[path];
+    float2 r2 = rand2(seed);
+    ps.random_seed[path] = seed + 2.0f;
+    float cx = (float)(px % rc.width) + r2.x, cy = (float)(px / rc.width) + r2.y;
+    float sx = cx / (float)rc.width, sy = cy / (float)rc.height;
+    sx = sx * 2.0f - 1.0f; sy = sy * 2.0f - 1.0f; sy *= -1.0f;
+    float aspect = (float)rc.width / (float)rc.height;
+    float sn, cs; pt_sincos(rc.fov_deg * 3.14159265358979323846f / 180.0f, sn, cs);
+    f3 local = F3(aspect * sx * sn, 1.0f, sy * sn);
+    f3 pos = F3(rc.cam_pos[0], rc.cam_pos[1], rc.cam_pos[2]);
+    f3 fwd = normalize3(F3(rc.cam_look_at[0], rc.cam_look_at[1], rc.cam_look_at[2]) - pos);
+    f3 right = normalize3(F3(fwd.y, -fwd.x, 0.0f));
+    f3 up = cross3(right, fwd);
+    f3 w = normalize3(local);
+    f3 d = (right * w.x + fwd * w.y) + up * w.z;
+    ps.path_o[path] = make_float4(pos.x, pos.y, pos.z, 0.0f);
+    ps.path_d[path] = make_float4(d.x, d.y, d.z, 0.0f);
+}
+
+// ============================================================================================
+// shade (material.js:75-120; scene.js:204-258 get_triangle_hit_info)
+// ============================================================================================
+__global__ __launch_bounds__(PT_BLOCK) void k_shade(PathState ps, RenderConst rc, SceneView sc, const StepHeader* __restrict__ hdr,
+                                                    const int32_t* __restrict__ mat_q) {
+    int q = blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (q >= hdr->n_material) return;
+    int path = mat_q[q];
+    f3 o = F3(ps.path_o[path]), d = F3(ps.path_d[path]);
+    int hit_obj = ps.hit_obj[path], hit_tri = ps.hit_tri[path];
+    const float4* ob = sc.objects + 8 * (int64_t)hit_obj;
+    float4 l0 = ob[0], l1 = ob[1], l2 = ob[2], inf = ob[3], w0 = ob[4], w1 = ob[5], w2 = ob[6];
+    f3 lo = xform(w0, w1, w2, o, 1.0f), ld = xform(w0, w1, w2, d, 0.0f);
+    const float4* tr = sc.tris + 3 * (int64_t)hit_tri;
+    f3 v0 = F3(tr[0]), v0v1 = F3(tr[1]) - v0, v0v2 = F3(tr[2]) - v0;
+    f3 pvec = cross3(ld, v0v2);
+    float det = dot3(v0v1, pvec), i_det = 1.0f / det;
+    f3 tvec = lo - v0;
+    f3 qvec = cross3(tvec, v0v1);
+    f3 ln = normalize3(cross3(v0v1, v0v2));
+    float ldist = dot3(v0v2, qvec) * i_det;
+    f3 lhit = lo + ld * ldist;
+    f3 whit = xform(l0, l1, l2, lhit, 1.0f);
+    f3 n = normalize3(xform(l0, l1, l2, ln, 0.0f));
+    float dist = length3(whit - o);
+    f3 hit_pos = o + d * dist;
+    f3 ov = __builtin_fabsf(n.x) > __builtin_fabsf(n.y) ? F3(-n.y, n.x, 0.0f) : F3(0.0f, -n.z, n.y);   // material.js:166-171
+    f3 o1 = normalize3(ov), o2 = normalize3(cross3(o1, n));
+    float seed = ps.random_seed[path];
+    float4 bp = make_float4(0.0f, 0.0f, 0.0f, 0.0f); f3 wi = F3(0.0f, 0.0f, 0.0f);
+    int mat = __float_as_int(inf.y);
+    if (mat == 0 || mat == 1) {                                                  // material.js:106-111
+        float2 r2 = rand2(seed); seed += 2.0f;
+        float rad = __builtin_sqrtf(fmax_(r2.x, 0.0f)), sn, cs;                    // material.js:141-151
+        pt_sincos(6.283185307179586f * r2.y, sn, cs);
+        float dx = rad * cs, dy = rad * sn;
+        float z = __builtin_sqrtf(fmax_(0.0f, (1.0f - dx * dx) - dy * dy));
+        wi = F3(dx, dy, z);
+        float a = mat == 0 ? ALBEDO0_POW : ALBEDO1_POW;
+        bp = make_float4(a, a, a, wi.z);
+    }
+    f3 nd = (o1 * wi.x + o2 * wi.y) + n * wi.z;
+    f3 no = hit_pos + n * 0.0001f;
+    ps.material_throughput_pdf[path] = bp;
+    ps.flags[path] |= 1u;
+    ps.random_seed[path] = seed;
+    ps.path_o[path] = make_float4(no.x, no.y, no.z, 0.0f);
+    ps.path_d[path] = make_float4(nd.x, nd.y, nd.z, 0.0f);
+}
+
+// ============================================================================================
+// extend (ray-trace.js:53-69; scene.js:313-515 intersect_bvh)
+// ============================================================================================
+// One ray per lane.  Traversal state lives in VGPRs; the traversal stack's first PT_LDS_STACK
+// entries live in LDS as [entry][thread] (bank = thread & 31 whatever the entry, and lanes l / l+32
+// are served in different LDS cycles, so divergent stack depths never conflict); deeper entries go
+// to an HBM spill laid out [entry][ray] so that equal depths coalesce.
+struct Trav {
+    int hit_obj, hit_tri; float hit_dist; int n_inner, n_leaf, n_enter, n_leave; int overflow;
+};
+
+// scene.js:508-515 with 1/d hoisted (it only changes when the ray changes space)
+__device__ __forceinline__ float slab(f3 low, f3 high, f3 o, f3 id) {
+    f3 f = (high - o) * id, n = (low - o) * id;
+    f3 tmax = max3(f, n), tmin = min3(f, n);
+    float t0 = fmax_(tmin.x, fmax_(tmin.y, tmin.z));
+    float t1 = fmin_(tmax.x, fmin_(tmax.y, tmax.z));
+    return (t1 >= t0) ? ((t1 < 0.0f) ? -1e30f : t0) : -1e30f;
+}
+// scene.js:478-506
+__device__ __forceinline__ float tri_hit(f3 o, f3 d, float4 a, float4 b, float4 c) {
+    f3 v0 = F3(a), v0v1 = F3(b) - v0, v0v2 = F3(c) - v0;
+    f3 pvec = cross3(d, v0v2);
+    float det = dot3(v0v1, pvec);
+    if (__builtin_fabsf(det) < 1e-10f) return -1.0f;
+    float i_det = 1.0f / det;
+    f3 tvec = o - v0;
+    float u = dot3(tvec, pvec) * i_det;
+    if (u < 0.0f || u > 1.0f) return -1.0f;
+    f3 qvec = cross3(tvec, v0v1);
+    float v = dot3(d, qvec) * i_det;
+    if (v < 0.0f || u + v > 1.0f) return -1.0f;
+    return dot3(v0v2, qvec) * i_det;
+}
+// scene.js:333-350 / :364-379: map o and the point o + d*hit_dist, renormalise d, recompute hit_dist
+__device__ __forceinline__ void switch_space(float4 r0, float4 r1, float4 r2, f3& o, f3& d, float& hit_dist) {
+    f3 hit_pos = o + d * hit_dist;
+    f3 new_o = xform(r0, r1, r2, o, 1.0f), new_h = xform(r0, r1, r2, hit_pos, 1.0f);
+    f3 nd = new_h - new_o;
+    hit_dist = length3(nd);
+    d = nd / hit_dist;
+    o = new_o;
+}
+
+template <bool COUNT>
+__device__ __forceinline__ Trav traverse(const SceneView& sc, f3 o, f3 d, int* lds_stack /* &[0][tid] */,
+                                         int32_t* spill /* &[0][ray] */, int64_t spill_stride) {
+    Trav R; R.n_inner = R.n_leaf = R.n_enter = R.n_leave = 0; R.overflow = 0;
+    float hit_dist = 1e6f; int hit_obj = -1, hit_tri = -1;
+    int sp = 0, node = 0, obj = -1, switch_pt = -1, iter = 0;
+    f3 id = rcp3(d);
+    while (sp >= 0) {
+        if (++iter > PT_MAX_ITERS) { R.overflow = 1; break; }
+        if (sp < switch_pt) {                                   // scene.js:330-355 leaving the object
+            const float4* ob = sc.objects + 8 * (int64_t)obj;
+            switch_space(ob[0], ob[1], ob[2], o, d, hit_dist);
+            id = rcp3(d); switch_pt = -1; obj = -1;
+            if (COUNT) R.n_leave++;
+        }
+        if (node < 0) {
+            if (obj < 0) {                                      // scene.js:357-379 entering an object
+                obj = -(node + 1);
+                const float4* ob = sc.objects + 8 * (int64_t)obj;
+                node = __float_as_int(ob[3].x); switch_pt = sp;
+                switch_space(ob[4], ob[5], ob[6], o, d, hit_dist);
+                id = rcp3(d);
+                if (COUNT) R.n_enter++;
+            } else {                                            // scene.js:380-391 triangle
+                int t = -(node + 1);
+                const float4* tr = sc.tris + 3 * (int64_t)t;
+                float dist = tri_hit(o, d, tr[0], tr[1], tr[2]);
+                if (dist > 0.0f && dist < hit_dist) { hit_dist = dist; hit_tri = t; hit_obj = obj; }
+                if (COUNT) R.n_leaf++;
+                sp -= 1;
+                node = sp < 0 ? 0 : (sp < PT_LDS_STACK ? lds_stack[sp * PT_BLOCK] : spill[(int64_t)(sp - PT_LDS_STACK) * spill_stride]);
+            }
+        } else {                                                // scene.js:392-439 inner node
+            const float4* nd = (obj < 0 ? sc.tlas : sc.blas) + 4 * (int64_t)node;
+            float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+            if (COUNT) R.n_inner++;
+            float l_dist = slab(F3(q0), F3(q1), o, id), r_dist = slab(F3(q2), F3(q3), o, id);
+            bool l_valid = l_dist != -1e30f && l_dist < hit_dist;
+            bool r_valid = r_dist != -1e30f && r_dist < hit_dist;
+            int l_child = __float_as_int(q0.w), r_child = __float_as_int(q2.w);
+            if (l_valid && r_valid) {
+                bool l_first = l_dist < r_dist;
+                int c_idx = l_first ? l_child : r_child, f_idx = l_first ? r_child : l_child;
+                if (sp >= PT_STACK_SIZE) { R.overflow = 1; break; }
+                if (sp < PT_LDS_STACK) lds_stack[sp * PT_BLOCK] = f_idx; else spill[(int64_t)(sp - PT_LDS_STACK) * spill_stride] = f_idx;
+                sp += 1; node = c_idx;
+            } else if (l_valid) node = l_child;
+            else if (r_valid)   node = r_child;
+            else {
+                sp -= 1;
+                node = sp < 0 ? 0 : (sp < PT_LDS_STACK ? lds_stack[sp * PT_BLOCK] : spill[(int64_t)(sp - PT_LDS_STACK) * spill_stride]);
+            }
+        }
+    }
+    if (obj >= 0) {                                             // scene.js:442-466
+        const float4* ob = sc.objects + 8 * (int64_t)obj;
+        switch_space(ob[0], ob[1], ob[2], o, d, hit_dist);
+        if (COUNT) R.n_leave++;
+    }
+    R.hit_obj = hit_obj; R.hit_tri = hit_tri; R.hit_dist = hit_dist;
+    return R;
+}
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    return v;
+}
+template <bool COUNT>
+__device__ __forceinline__ void publish_counts(const Trav& r, bool active, StepHeader* hdr) {
+    if (__any(active && r.overflow)) {
+        unsigned long long ov = wave_sum(active ? (unsigned long long)r.overflow : 0ull);
+        if (lane_id() == 0) atomicAdd(&hdr->overflow, ov);
+    }
+    if (COUNT) {
+        unsigned long long a = wave_sum(active ? r.n_inner : 0), b = wave_sum(active ? r.n_leaf : 0),
+                           c = wave_sum(active ? r.n_enter : 0), e = wave_sum(active ? r.n_leave : 0);
+        if (lane_id() == 0) { atomicAdd(&hdr->visits[0], a); atomicAdd(&hdr->visits[1], b); atomicAdd(&hdr->visits[2], c); atomicAdd(&hdr->visits[3], e); }
+    }
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(PT_BLOCK) void k_extend_queue(PathState ps, SceneView sc, StepHeader* hdr, const int32_t* __restrict__ cam_q,
+                                                           const int32_t* __restrict__ mat_q, int32_t* spill, int64_t spill_stride) {
+    __shared__ int s_stack[PT_LDS_STACK * PT_BLOCK];
+    int q = blockIdx.x * PT_BLOCK + threadIdx.x;
+    int n_cam = hdr->n_camera, n_rays = n_cam + hdr->n_material;
+    bool active = q < n_rays;
+    Trav r; r.overflow = 0; r.n_inner = r.n_leaf = r.n_enter = r.n_leave = 0;
+    if (active) {
+        int path = q < n_cam ? cam_q[q] : mat_q[q - n_cam];
+        r = traverse<COUNT>(sc, F3(ps.path_o[path]), F3(ps.path_d[path]), s_stack + threadIdx.x, spill + q, spill_stride);
+        ps.hit_obj[path] = r.hit_obj; ps.hit_tri[path] = r.hit_tri;
+    }
+    publish_counts<COUNT>(r, active, hdr);
+}
+
+__global__ __launch_bounds__(PT_BLOCK) void k_extend_direct(SceneView sc, const float4* __restrict__ o4, const float4* __restrict__ d4, int n,
+                                                            int32_t* __restrict__ hit_obj, int32_t* __restrict__ hit_tri,
+                                                            float* __restrict__ hit_dist, int4* __restrict__ counts4, int32_t* spill,
+                                                            int64_t spill_stride, StepHeader* hdr) {
+    __shared__ int s_stack[PT_LDS_STACK * PT_BLOCK];
+    int q = blockIdx.x * PT_BLOCK + threadIdx.x;
+    bool active = q < n;
+    Trav r; r.overflow = 0; r.n_inner = r.n_leaf = r.n_enter = r.n_leave = 0;
+    if (active) {
+        r = traverse<true>(sc, F3(o4[q]), F3(d4[q]), s_stack + threadIdx.x, spill + q, spill_stride);
+        hit_obj[q] = r.hit_obj; hit_tri[q] = r.hit_tri; hit_dist[q] = r.hit_dist;
+        if (counts4) counts4[q] = make_int4(r.n_inner, r.n_leaf, r.n_enter, r.n_leave);
+    }
+    publish_counts<false>(r, active, hdr);
+}
+
+// ============================================================================================
+// tonemap (display.js:98-113) + unorm8 store of the canvas
+// ============================================================================================
+__global__ __launch_bounds__(PT_BLOCK) void k_tonemap(const float4* __restrict__ image, int64_t n, uint32_t* __restrict__ rgba8) {
+    int64_t i = (int64_t)blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float4 p = image[i];
+    float c[3] = { p.x / p.w, p.y / p.w, p.z / p.w };
+    float lum = (c[0] * 0.2126f + c[1] * 0.7152f) + c[2] * 0.0722f;
+    uint32_t out = 0xff000000u;
+    for (int k = 0; k < 3; k++) {
+        float v = powf(c[k] / (1.0f + lum), 1.0f / 2.2f);
+        if (!(v > 0.0f)) v = 0.0f;
+        if (v > 1.0f) v = 1.0f;
+        out |= (uint32_t)(v * 255.0f + 0.5f) << (8 * k);
+    }
+    rgba8[i] = out;
+}
+
+// ---- launchers -------------------------------------------------------------------------------
+size_t ptk_spill_ints(int64_t n_rays) {
+    int64_t padded = (n_rays + PT_BLOCK - 1) / PT_BLOCK * PT_BLOCK;
+    return (size_t)padded * (PT_STACK_SIZE - PT_LDS_STACK);
+}
+static int64_t spill_stride_for(int64_t n_rays) { return (n_rays + PT_BLOCK - 1) / PT_BLOCK * PT_BLOCK; }
+
+void ptk_logic(const PathState& ps, const RenderConst& rc, int first_sample, float* image, uint8_t* code, int4* blk_counts, hipStream_t s) {
+    hipLaunchKernelGGL(k_logic, grid_for(rc.num_paths), dim3(PT_BLOCK), 0, s, ps, rc, first_sample, image, code, blk_counts);
+}
+void ptk_scan(const int4* blk_counts, int4* blk_offsets, int nblocks, StepHeader* hdr, hipStream_t s) {
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, blk_counts, blk_offsets, nblocks, hdr);
+}
+void ptk_compact(const PathState& ps, const RenderConst& rc, const uint8_t* code, const int4* blk_offsets, const StepHeader* hdr,
+                 int32_t* cam_q, int32_t* mat_q, hipStream_t s) {
+    hipLaunchKernelGGL(k_compact, grid_for(rc.num_paths), dim3(PT_BLOCK), 0, s, ps, rc, code, blk_offsets, hdr, cam_q, mat_q);
+}
+void ptk_generate(const PathState& ps, const RenderConst& rc, const StepHeader* hdr, const int32_t* cam_q, hipStream_t s) {
+    hipLaunchKernelGGL(k_generate, grid_for(rc.num_paths), dim3(PT_BLOCK), 0, s, ps, rc, hdr, cam_q);
+}
+void ptk_shade(const PathState& ps, const RenderConst& rc, const SceneView& sc, const StepHeader* hdr, const int32_t* mat_q, hipStream_t s) {
+    hipLaunchKernelGGL(k_shade, grid_for(rc.num_paths), dim3(PT_BLOCK), 0, s, ps, rc, sc, hdr, mat_q);
+}
+void ptk_extend_queue(const PathState& ps, const RenderConst& rc, const SceneView& sc, StepHeader* hdr, const int32_t* cam_q,
+                      const int32_t* mat_q, int32_t* spill, int count, hipStream_t s) {
+    int64_t stride = spill_stride_for(rc.num_paths);
+    if (count) hipLaunchKernelGGL(k_extend_queue<true>, grid_for(rc.num_paths), dim3(PT_BLOCK), 0, s, ps, sc, hdr, cam_q, mat_q, spill, stride);
+    else       hipLaunchKernelGGL(k_extend_queue<false>, grid_for(rc.num_paths), dim3(PT_BLOCK), 0, s, ps, sc, hdr, cam_q, mat_q, spill, stride);
+}
+void ptk_extend_direct(const SceneView& sc, const float4* o4, const float4* d4, int n, int32_t* hit_obj, int32_t* hit_tri,
+                       float* hit_dist, int4* counts4, int32_t* spill, StepHeader* hdr, hipStream_t s) {
+    hipLaunchKernelGGL(k_extend_direct, grid_for(n), dim3(PT_BLOCK), 0, s, sc, o4, d4, n, hit_obj, hit_tri, hit_dist, counts4, spill,
+                       spill_stride_for(n), hdr);
+}
+void ptk_tonemap(const float4* image, int64_t n_pixels, uint32_t* rgba8, hipStream_t s) {
+    hipLaunchKernelGGL(k_tonemap, grid_for(n_pixels), dim3(PT_BLOCK), 0, s, image, n_pixels, rgba8);
+}
