@@ -101,6 +101,10 @@ typedef struct {
 /* replaces: initPathTracer({device, scene, image, camera, settings}) (path-tracer.js:1-47,207-329) */
 int pt_render_init(pt_ctx* ctx, const pt_render_params* params);
 
+/* Start the same render again without reallocating: every buffer pt_render_init created is zeroed
+ * again, as a second initPathTracer() call would find them (new GPUBuffers are zero-filled). */
+int pt_render_reset(pt_ctx* ctx);
+
 typedef struct {
     int64_t n_camera;     /* stage_2_queue_size[0] after logic (path-tracer.js:174) */
     int64_t n_material;   /* stage_2_queue_size[1] */

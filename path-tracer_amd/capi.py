@@ -56,6 +56,7 @@ SIGNATURES = {
     "pt_get_mesh_perm": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
     "pt_trace_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pt_render_init": (C.c_int, [C.c_void_p, C.POINTER(PtRenderParams)]),
+    "pt_render_reset": (C.c_int, [C.c_void_p]),
     "pt_render_step": (C.c_int, [C.c_void_p, C.POINTER(PtStepStats)]),
     "pt_render_run": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.POINTER(PtRunStats)]),
     "pt_image_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),

@@ -39,7 +39,7 @@ struct pt_ctx {
     float* d_image = nullptr; bool own_image = false; uint8_t* d_code = nullptr;
     int4 *d_blk_counts = nullptr, *d_blk_offsets = nullptr; int32_t *d_cam_q = nullptr, *d_mat_q = nullptr, *d_spill = nullptr;
     StepHeader* d_hdr = nullptr; StepHeader* h_hdr = nullptr; int nblocks = 0; int64_t step = 0;
-    std::vector<void*> render_allocs; std::vector<hipEvent_t> events;
+    std::vector<std::pair<void*, size_t>> render_allocs; std::vector<hipEvent_t> events; int64_t ticket_begin = 0;
 };
 
 namespace {
@@ -108,7 +108,7 @@ void free_scene(pt_ctx* c) {
     c->d_blas_nodes = c->d_blas_tris = c->d_tlas_nodes = c->d_objects = nullptr; c->d_tlas_perm = nullptr; c->scene_built = false;
 }
 void free_render(pt_ctx* c) {
-    for (void* p : c->render_allocs) dfree(p);
+    for (auto& p : c->render_allocs) dfree(p.first);
     c->render_allocs.clear();
     if (c->h_hdr) { (void)hipHostFree(c->h_hdr); c->h_hdr = nullptr; }
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
@@ -118,7 +118,7 @@ void free_render(pt_ctx* c) {
 
 template <typename T> int ralloc(pt_ctx* c, T** p, size_t count) {
     int rc = dalloc(c, p, count, true);
-    if (rc == PT_OK) c->render_allocs.push_back(*p);
+    if (rc == PT_OK) c->render_allocs.push_back({*p, std::max<size_t>(count, 1) * sizeof(T)});
     return rc;
 }
 
@@ -139,6 +139,18 @@ void enqueue_step(pt_ctx* c, int count_visits, hipEvent_t ev0, hipEvent_t ev1) {
     ptk_extend_queue(c->ps, c->rc, sv, c->d_hdr, c->d_cam_q, c->d_mat_q, c->d_spill, count_visits, c->stream);
     if (ev1) (void)hipEventRecord(ev1, c->stream);
     c->step++;
+}
+
+// fresh StepHeader: no step taken, ticket counter at this GPU's first ticket
+int write_header(pt_ctx* c) {
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    StepHeader h; memset(&h, 0, sizeof h);
+    h.first_empty_step = -1; h.pixel_counter = c->ticket_begin;
+    *c->h_hdr = h;
+    HIPOK(c, hipMemcpyAsync(c->d_hdr, c->h_hdr, sizeof h, hipMemcpyHostToDevice, c->stream));
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    c->step = 0;
+    return PT_OK;
 }
 
 }  // namespace
@@ -341,7 +353,7 @@ int pt_render_init(pt_ctx* c, const pt_render_params* p) {
     int64_t total = ((int64_t)p->width * p->height * p->spp + PT_SAMPLES_PER_TICKET - 1) / PT_SAMPLES_PER_TICKET;   // logic.js:177
     rc.slot_base = p->slot_base;
     rc.ticket_limit = p->ticket_end >= 0 ? p->ticket_end : total;
-    int64_t ticket_begin = p->ticket_end >= 0 ? p->ticket_begin : 0;
+    c->ticket_begin = p->ticket_end >= 0 ? p->ticket_begin : 0;
     int r; size_t n = (size_t)np;
     PathState& ps = c->ps;   // zero-filled like a new GPUBuffer (path-tracer.js:271-275)
     if ((r = ralloc(c, &ps.pixel_index, n)) || (r = ralloc(c, &ps.num_bounces, n)) || (r = ralloc(c, &ps.random_seed, n)) ||
@@ -358,13 +370,17 @@ int pt_render_init(pt_ctx* c, const pt_render_params* p) {
     if (p->image_dev) { c->d_image = (float*)p->image_dev; c->own_image = false; HIPOK(c, hipMemsetAsync(c->d_image, 0, img_floats * 4, c->stream)); }
     else { if ((r = ralloc(c, &c->d_image, img_floats))) return r; c->own_image = true; }
     HIPOK(c, hipHostMalloc((void**)&c->h_hdr, sizeof(StepHeader), hipHostMallocDefault));
-    StepHeader h; memset(&h, 0, sizeof h);
-    h.first_empty_step = -1; h.pixel_counter = ticket_begin;
-    *c->h_hdr = h;
-    HIPOK(c, hipMemcpyAsync(c->d_hdr, c->h_hdr, sizeof h, hipMemcpyHostToDevice, c->stream));
-    HIPOK(c, hipStreamSynchronize(c->stream));
-    c->step = 0; c->render_ready = true;
-    return PT_OK;
+    c->render_ready = true;
+    return write_header(c);
+}
+
+int pt_render_reset(pt_ctx* c) {
+    if (!c) return PT_ERR_ARG;
+    if (!c->render_ready) return fail(c, PT_ERR_STATE, "pt_render_reset: pt_render_init has not been called");
+    HIPOK(c, hipSetDevice(c->device));
+    for (auto& a : c->render_allocs) HIPOK(c, hipMemsetAsync(a.first, 0, a.second, c->stream));
+    if (!c->own_image) HIPOK(c, hipMemsetAsync(c->d_image, 0, (size_t)c->rc.width * c->rc.height * 16, c->stream));
+    return write_header(c);
 }
 
 int pt_render_step(pt_ctx* c, pt_step_stats* stats) {

@@ -297,6 +297,10 @@ class PathTracer:
         self.width, self.height = p.width, p.height
         self.device.call("pt_render_init", C.byref(p))
 
+    def reset(self):
+        """Render the same frame again (what calling initPathTracer a second time gives), no reallocation."""
+        self.device.call("pt_render_reset")
+
     def step(self, want_stats=True):
         """path-tracer.js:49-123."""
         st = capi.PtStepStats()
