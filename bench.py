@@ -81,10 +81,9 @@ def main():
     info = scene.info()
 
     # per-GPU share: full spp each, distinct ticket range and RNG streams
-    tickets = (w * h * spp + 7) // 8
     image = torch.zeros(h * w * 4, dtype=torch.float32, device="cuda")
-    settings = {"samples": spp * world, "numPaths": args.paths, "slotBase": rank * args.paths,
-                "ticketBegin": rank * tickets, "ticketEnd": (rank + 1) * tickets, "imageDev": image.data_ptr()}
+    settings = pta.multigpu.weak_share(rank, world, w, h, spp, args.paths)
+    settings["imageDev"] = image.data_ptr()
     pt = pta.init_path_tracer({"device": dev, "scene": scene, "image": {"width": w, "height": h}, "camera": desc["camera"], "settings": settings})
 
     def barrier():
@@ -95,8 +94,7 @@ def main():
     def one_step(timed, count):
         pt.reset()
         rs = pt.run(time_extend=timed, count_bytes=count)
-        if world > 1:
-            dist.reduce(image, dst=0, op=dist.ReduceOp.SUM)    # RCCL over xGMI: W*H*4 floats
+        pta.multigpu.reduce_image(image, dst=0)                # RCCL over xGMI: W*H*4 floats (no-op at N=1)
         return rs
 
     trav_bytes = 0

@@ -1,0 +1,223 @@
+// addon.cc -- thin N-API binding of the C ABI in include/pt_amd.h for the headless Node.js host.
+// One JS function per pt_* entry point; typed arrays go through as raw pointers, nothing is computed here.
+// Built with plain g++ against /usr/include/node/node_api.h (N-API 8, Node 12) and linked to ../libpt_amd.so.
+#include <node_api.h>
+#include <stdint.h>
+#include <string.h>
+#include <string>
+#include "pt_amd.h"
+
+#define NAPI_OK(call)                                                                  \
+    do {                                                                               \
+        if ((call) != napi_ok) { napi_throw_error(env, nullptr, "N-API call failed: " #call); return nullptr; } \
+    } while (0)
+
+static napi_value throw_pt(napi_env env, pt_ctx* c, const char* what, int rc) {
+    std::string msg = std::string(what) + " failed (" + std::to_string(rc) + "): " + pt_last_error(c);
+    napi_throw_error(env, nullptr, msg.c_str());
+    return nullptr;
+}
+
+static bool get_args(napi_env env, napi_callback_info info, size_t want, napi_value* argv) {
+    size_t argc = want;
+    if (napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr) != napi_ok || argc < want) {
+        napi_throw_type_error(env, nullptr, "wrong number of arguments");
+        return false;
+    }
+    return true;
+}
+static pt_ctx* ctx_of(napi_env env, napi_value v) {
+    void* p = nullptr;
+    if (napi_get_value_external(env, v, &p) != napi_ok || !p) { napi_throw_type_error(env, nullptr, "expected a pt context"); return nullptr; }
+    return *(pt_ctx**)p;
+}
+// typed array -> pointer + byte length (null for JS null/undefined)
+static bool ta(napi_env env, napi_value v, void** data, size_t* bytes) {
+    napi_valuetype t; napi_typeof(env, v, &t);
+    *data = nullptr; *bytes = 0;
+    if (t == napi_null || t == napi_undefined) return true;
+    bool is_ta = false; napi_is_typedarray(env, v, &is_ta);
+    if (!is_ta) { napi_throw_type_error(env, nullptr, "expected a TypedArray"); return false; }
+    napi_typedarray_type tt; size_t len; napi_value ab; size_t off;
+    if (napi_get_typedarray_info(env, v, &tt, &len, data, &ab, &off) != napi_ok) return false;
+    static const size_t esz[] = {1, 1, 1, 2, 2, 4, 4, 4, 8, 8, 8};
+    *bytes = len * esz[tt];
+    return true;
+}
+static int64_t i64(napi_env env, napi_value v) { int64_t x = 0; napi_get_value_int64(env, v, &x); return x; }
+static double f64(napi_env env, napi_value v) { double x = 0; napi_get_value_double(env, v, &x); return x; }
+static napi_value num(napi_env env, double x) { napi_value v; napi_create_double(env, x, &v); return v; }
+static void set(napi_env env, napi_value obj, const char* k, double x) { napi_set_named_property(env, obj, k, num(env, x)); }
+static double prop(napi_env env, napi_value obj, const char* k, double dflt) {
+    bool has = false; napi_has_named_property(env, obj, k, &has);
+    if (!has) return dflt;
+    napi_value v; napi_get_named_property(env, obj, k, &v);
+    napi_valuetype t; napi_typeof(env, v, &t);
+    return t == napi_number ? f64(env, v) : dflt;
+}
+static void prop3(napi_env env, napi_value obj, const char* k, float out[3]) {
+    napi_value a; napi_get_named_property(env, obj, k, &a);
+    for (uint32_t i = 0; i < 3; i++) { napi_value e; napi_get_element(env, a, i, &e); out[i] = (float)f64(env, e); }
+}
+
+static void finalize_ctx(napi_env, void* data, void*) {
+    pt_ctx** h = (pt_ctx**)data;
+    if (*h) pt_destroy(*h);
+    delete h;
+}
+
+// create(deviceId) -> context handle            [pt_create]
+static napi_value Create(napi_env env, napi_callback_info info) {
+    napi_value a[1]; if (!get_args(env, info, 1, a)) return nullptr;
+    pt_ctx* c = nullptr; int rc = pt_create((int)i64(env, a[0]), &c);
+    if (rc < 0) return throw_pt(env, nullptr, "pt_create", rc);
+    pt_ctx** h = new pt_ctx*(c);
+    napi_value ext; NAPI_OK(napi_create_external(env, h, finalize_ctx, nullptr, &ext));
+    return ext;
+}
+// destroy(ctx)                                  [pt_destroy]
+static napi_value Destroy(napi_env env, napi_callback_info info) {
+    napi_value a[1]; if (!get_args(env, info, 1, a)) return nullptr;
+    void* p = nullptr; napi_get_value_external(env, a[0], &p);
+    if (p && *(pt_ctx**)p) { pt_destroy(*(pt_ctx**)p); *(pt_ctx**)p = nullptr; }
+    return nullptr;
+}
+// meshUpload(ctx, Float32Array tris12, Float32Array bounds6) -> handle     [pt_mesh_upload]
+static napi_value MeshUpload(napi_env env, napi_callback_info info) {
+    napi_value a[3]; if (!get_args(env, info, 3, a)) return nullptr;
+    pt_ctx* c = ctx_of(env, a[0]); if (!c) return nullptr;
+    void *t, *b; size_t tb, bb;
+    if (!ta(env, a[1], &t, &tb) || !ta(env, a[2], &b, &bb)) return nullptr;
+    if (bb != 24 || tb % 48) { napi_throw_range_error(env, nullptr, "meshUpload: tris must be 12 floats per triangle, bounds 6 floats"); return nullptr; }
+    int rc = pt_mesh_upload(c, (const float*)t, (int64_t)(tb / 48), (const float*)b);
+    if (rc < 0) return throw_pt(env, c, "pt_mesh_upload", rc);
+    return num(env, rc);
+}
+// sceneBuild(ctx, ArrayBuffer-backed typed array of pt_instance records (40 words each), n)   [pt_scene_build]
+static napi_value SceneBuild(napi_env env, napi_callback_info info) {
+    napi_value a[3]; if (!get_args(env, info, 3, a)) return nullptr;
+    pt_ctx* c = ctx_of(env, a[0]); if (!c) return nullptr;
+    void* d; size_t nb; if (!ta(env, a[1], &d, &nb)) return nullptr;
+    int n = (int)i64(env, a[2]);
+    if (nb < (size_t)n * sizeof(pt_instance)) { napi_throw_range_error(env, nullptr, "sceneBuild: instance buffer too small"); return nullptr; }
+    int rc = pt_scene_build(c, (const pt_instance*)d, n);
+    if (rc < 0) return throw_pt(env, c, "pt_scene_build", rc);
+    return nullptr;
+}
+// sceneInfo(ctx) -> {nTris, nObjects, nMeshesUsed}                          [pt_scene_get_info]
+static napi_value SceneInfo(napi_env env, napi_callback_info info) {
+    napi_value a[1]; if (!get_args(env, info, 1, a)) return nullptr;
+    pt_ctx* c = ctx_of(env, a[0]); if (!c) return nullptr;
+    pt_scene_info si; int rc = pt_scene_get_info(c, &si);
+    if (rc < 0) return throw_pt(env, c, "pt_scene_get_info", rc);
+    napi_value o; napi_create_object(env, &o);
+    set(env, o, "nTris", (double)si.n_tris); set(env, o, "nObjects", si.n_objects); set(env, o, "nMeshesUsed", si.n_meshes_used);
+    return o;
+}
+// readBuffer(ctx, which, typedArray[, mesh]): which in blasNodes|blasTris|tlasNodes|objects|tlasPerm|meshPerm   [pt_get_*]
+static napi_value ReadBuffer(napi_env env, napi_callback_info info) {
+    napi_value a[4]; size_t argc = 4; napi_get_cb_info(env, info, &argc, a, nullptr, nullptr);
+    if (argc < 3) { napi_throw_type_error(env, nullptr, "readBuffer(ctx, which, out[, mesh])"); return nullptr; }
+    pt_ctx* c = ctx_of(env, a[0]); if (!c) return nullptr;
+    char which[32]; size_t wl; napi_get_value_string_utf8(env, a[1], which, sizeof which, &wl);
+    void* d; size_t nb; if (!ta(env, a[2], &d, &nb)) return nullptr;
+    int rc = PT_ERR_ARG;
+    if (!strcmp(which, "blasNodes")) rc = pt_get_blas_nodes(c, (pt_bvh_node*)d, (int64_t)(nb / 64));
+    else if (!strcmp(which, "blasTris")) rc = pt_get_blas_tris(c, (pt_triangle*)d, (int64_t)(nb / 48));
+    else if (!strcmp(which, "tlasNodes")) rc = pt_get_tlas_nodes(c, (pt_bvh_node*)d, (int64_t)(nb / 64));
+    else if (!strcmp(which, "objects")) rc = pt_get_objects(c, (pt_object*)d, (int64_t)(nb / 128));
+    else if (!strcmp(which, "tlasPerm")) rc = pt_get_tlas_perm(c, (int32_t*)d, (int64_t)(nb / 4));
+    else if (!strcmp(which, "meshPerm") && argc == 4) rc = pt_get_mesh_perm(c, (int)i64(env, a[3]), (int32_t*)d, (int64_t)(nb / 4));
+    if (rc < 0) return throw_pt(env, c, "readBuffer", rc);
+    return nullptr;
+}
+// traceRays(ctx, Float32Array o3, Float32Array d3, Int32Array hitObj, Int32Array hitTri, Float32Array hitDist|null)   [pt_trace_rays]
+static napi_value TraceRays(napi_env env, napi_callback_info info) {
+    napi_value a[6]; if (!get_args(env, info, 6, a)) return nullptr;
+    pt_ctx* c = ctx_of(env, a[0]); if (!c) return nullptr;
+    void* p[5]; size_t nb[5];
+    for (int i = 0; i < 5; i++) if (!ta(env, a[1 + i], &p[i], &nb[i])) return nullptr;
+    int64_t n = (int64_t)(nb[0] / 12);
+    if (nb[1] != nb[0] || (p[2] && nb[2] != (size_t)n * 4) || (p[3] && nb[3] != (size_t)n * 4) || (p[4] && nb[4] != (size_t)n * 4)) {
+        napi_throw_range_error(env, nullptr, "traceRays: array sizes disagree"); return nullptr;
+    }
+    int rc = pt_trace_rays(c, (const float*)p[0], (const float*)p[1], n, (int32_t*)p[2], (int32_t*)p[3], (float*)p[4], nullptr);
+    if (rc < 0) return throw_pt(env, c, "pt_trace_rays", rc);
+    return nullptr;
+}
+// renderInit(ctx, {width,height,position[3],lookAt[3],fov,samples,numPaths,slotBase,ticketBegin,ticketEnd})   [pt_render_init]
+static napi_value RenderInit(napi_env env, napi_callback_info info) {
+    napi_value a[2]; if (!get_args(env, info, 2, a)) return nullptr;
+    pt_ctx* c = ctx_of(env, a[0]); if (!c) return nullptr;
+    pt_render_params p; memset(&p, 0, sizeof p);
+    p.width = (int32_t)prop(env, a[1], "width", 0); p.height = (int32_t)prop(env, a[1], "height", 0);
+    prop3(env, a[1], "position", p.cam_pos); prop3(env, a[1], "lookAt", p.cam_look_at);
+    p.fov_deg = (float)prop(env, a[1], "fov", 60); p.spp = (int32_t)prop(env, a[1], "samples", 8);
+    p.num_paths = (int32_t)prop(env, a[1], "numPaths", 0); p.slot_base = (int64_t)prop(env, a[1], "slotBase", 0);
+    p.ticket_begin = (int64_t)prop(env, a[1], "ticketBegin", 0); p.ticket_end = (int64_t)prop(env, a[1], "ticketEnd", -1);
+    int rc = pt_render_init(c, &p);
+    if (rc < 0) return throw_pt(env, c, "pt_render_init", rc);
+    return nullptr;
+}
+// renderReset(ctx)                                                          [pt_render_reset]
+static napi_value RenderReset(napi_env env, napi_callback_info info) {
+    napi_value a[1]; if (!get_args(env, info, 1, a)) return nullptr;
+    pt_ctx* c = ctx_of(env, a[0]); if (!c) return nullptr;
+    int rc = pt_render_reset(c);
+    if (rc < 0) return throw_pt(env, c, "pt_render_reset", rc);
+    return nullptr;
+}
+// renderStep(ctx) -> {camera, material, rays, step}                         [pt_render_step]
+static napi_value RenderStep(napi_env env, napi_callback_info info) {
+    napi_value a[1]; if (!get_args(env, info, 1, a)) return nullptr;
+    pt_ctx* c = ctx_of(env, a[0]); if (!c) return nullptr;
+    pt_step_stats st; int rc = pt_render_step(c, &st);
+    if (rc < 0) return throw_pt(env, c, "pt_render_step", rc);
+    napi_value o; napi_create_object(env, &o);
+    set(env, o, "camera", (double)st.n_camera); set(env, o, "material", (double)st.n_material);
+    set(env, o, "rays", (double)st.n_rays); set(env, o, "step", (double)st.step_index);
+    return o;
+}
+// renderRun(ctx, maxSteps, flags) -> stats                                  [pt_render_run]
+static napi_value RenderRun(napi_env env, napi_callback_info info) {
+    napi_value a[3]; if (!get_args(env, info, 3, a)) return nullptr;
+    pt_ctx* c = ctx_of(env, a[0]); if (!c) return nullptr;
+    pt_run_stats rs; int rc = pt_render_run(c, i64(env, a[1]), (int)i64(env, a[2]), &rs);
+    if (rc < 0) return throw_pt(env, c, "pt_render_run", rc);
+    napi_value o; napi_create_object(env, &o);
+    set(env, o, "steps", (double)rs.steps); set(env, o, "totalRays", (double)rs.total_rays); set(env, o, "totalSamples", (double)rs.total_samples);
+    set(env, o, "stackOverflows", (double)rs.stack_overflows); set(env, o, "extendMs", rs.extend_ms);
+    set(env, o, "extendLaunches", (double)rs.extend_launches); set(env, o, "traversalBytes", (double)rs.traversal_bytes);
+    return o;
+}
+// imageRead(ctx, Float32Array rgba)                                         [pt_image_read]
+static napi_value ImageRead(napi_env env, napi_callback_info info) {
+    napi_value a[2]; if (!get_args(env, info, 2, a)) return nullptr;
+    pt_ctx* c = ctx_of(env, a[0]); if (!c) return nullptr;
+    void* d; size_t nb; if (!ta(env, a[1], &d, &nb)) return nullptr;
+    int rc = pt_image_read(c, (float*)d, (int64_t)(nb / 4));
+    if (rc < 0) return throw_pt(env, c, "pt_image_read", rc);
+    return nullptr;
+}
+// tonemap(ctx, Uint8Array rgba8)                                            [pt_tonemap_rgba8 on the ctx image]
+static napi_value Tonemap(napi_env env, napi_callback_info info) {
+    napi_value a[2]; if (!get_args(env, info, 2, a)) return nullptr;
+    pt_ctx* c = ctx_of(env, a[0]); if (!c) return nullptr;
+    void* d; size_t nb; if (!ta(env, a[1], &d, &nb)) return nullptr;
+    int rc = pt_tonemap_rgba8(c, nullptr, 0, 0, (uint8_t*)d);
+    if (rc < 0) return throw_pt(env, c, "pt_tonemap_rgba8", rc);
+    return nullptr;
+}
+
+static napi_value Init(napi_env env, napi_value exports) {
+    struct { const char* name; napi_callback fn; } fns[] = {
+        {"create", Create}, {"destroy", Destroy}, {"meshUpload", MeshUpload}, {"sceneBuild", SceneBuild}, {"sceneInfo", SceneInfo},
+        {"readBuffer", ReadBuffer}, {"traceRays", TraceRays}, {"renderInit", RenderInit}, {"renderReset", RenderReset},
+        {"renderStep", RenderStep}, {"renderRun", RenderRun}, {"imageRead", ImageRead}, {"tonemap", Tonemap}};
+    for (auto& f : fns) {
+        napi_value v; napi_create_function(env, f.name, NAPI_AUTO_LENGTH, f.fn, nullptr, &v);
+        napi_set_named_property(env, exports, f.name, v);
+    }
+    return exports;
+}
+NAPI_MODULE(pt_amd, Init)

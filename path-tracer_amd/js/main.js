@@ -1,0 +1,62 @@
+#!/usr/bin/env node
+// main.js -- headless counterpart of the reference's scripts/main.js: same call sequence
+// (registerMesh x k -> instanceMesh x m -> await build() -> initPathTracer -> initDisplay -> loop { await step(); draw() }),
+// no browser.  The reference's demo meshes (cow / bunny / buddha) are not distributed with it, so the demo scene is
+// the floor it does bundle under a lattice of generated boxes standing in for the 100 instanced meshes (main.js:25-33).
+//   node main.js [--width W] [--height H] [--samples S] [--paths N] [--grid G] [--out frame.png] [--json]
+"use strict"
+const pt = require("./pt-host.js")
+
+const FLOOR = "v -10.0 -10.0 0.0\nv  10.0 -10.0 0.0\nv  10.0  10.0 0.0\nv -10.0  10.0 0.0\n\nf 1 2 3\nf 1 3 4"
+const BOX = ["v -0.5 -0.5 0", "v 0.5 -0.5 0", "v 0.5 0.5 0", "v -0.5 0.5 0", "v -0.5 -0.5 1.4", "v 0.5 -0.5 1.4", "v 0.5 0.5 1.4", "v -0.5 0.5 1.4",
+             "f 1 4 3 2", "f 5 6 7 8", "f 1 2 6 5", "f 3 4 8 7", "f 1 5 8 4", "f 2 3 7 6"].join("\n")
+
+function arg(name, dflt) {
+    const i = process.argv.indexOf("--" + name)
+    return i > 0 ? (process.argv[i + 1] === undefined || process.argv[i + 1].startsWith("--") ? true : process.argv[i + 1]) : dflt
+}
+
+async function main() {
+    const width = +arg("width", 512), height = +arg("height", 512), samples = +arg("samples", 16), grid = +arg("grid", 10)
+    const device = pt.requestDevice(+arg("device", 0))
+    const scene = pt.initScene(device)
+    const t0 = Date.now()
+
+    const box = scene.registerMesh({ file: BOX })
+    const floor = scene.registerMesh({ file: FLOOR })
+    let lcg = 12345                                  // seeded stand-in for Math.random() (main.js:28) so runs are repeatable
+    for (let i = 0; i < grid * grid; i++) {
+        lcg = (Math.imul(lcg, 1664525) + 1013904223) >>> 0
+        scene.instanceMesh(box, [(i % grid) * 2, Math.floor(i / grid) * 2, -1.3], [0, 0, lcg / 4294967296 * Math.PI * 2.], [1, 1, 1], 1)
+    }
+    scene.instanceMesh(floor, [10, 10, -1.3], [0, 0, 0], [5, 5, 5], 0)
+    await scene.build()
+
+    const tracer = pt.initPathTracer({
+        device, scene,
+        image: { width, height },
+        camera: { lookAt: [10, 10, 0], position: [15, 15, 5], fov: 60 },     // main.js:42-46
+        settings: { samples, numPaths: +arg("paths", 0) },
+    })
+    const display = pt.initDisplay({ device, canvas: arg("out", null), image: { buffer: tracer.getImageBuffer(), width, height } })
+
+    // the reference's frame loop never learns that the render finished (main.js:61-72); headless, it stops on empty queues
+    let steps = 0, rays = 0
+    const t1 = Date.now()
+    for (;;) {
+        const st = await tracer.step()
+        steps++; rays += st.rays
+        if (st.camera + st.material === 0) break
+    }
+    const t2 = Date.now()
+    const rgba = display.draw()
+    const img = tracer.readImage()
+    let wsum = 0, rsum = 0
+    for (let i = 0; i < width * height; i++) { wsum += img[4 * i + 3]; rsum += img[4 * i] }
+    const report = { width, height, samples, steps, rays, buildMs: t1 - t0, renderMs: t2 - t1, sampleCount: wsum, radianceSum: rsum,
+                     firstPixel: Array.from(rgba.slice(0, 4)), info: scene.kernels.getSceneBindGroupInfo() }
+    console.log(arg("json", false) ? JSON.stringify(report) : report)
+    device.destroy()
+}
+
+main().catch(e => { console.error(e.message || e); process.exit(1) })

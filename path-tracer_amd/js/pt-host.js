@@ -1,0 +1,184 @@
+// pt-host.js -- headless Node.js host of the MI355X path tracer.
+//
+// Keeps the reference's three entry points and call sequence (main.js:16-72):
+//     initScene(device)       -> { registerMesh, instanceMesh, build, kernels }        scene.js:1,13
+//     initPathTracer(params)  -> { step, getImageBuffer, run, readImage }               path-tracer.js:1,47
+//     initDisplay(params)     -> { draw }                                               display.js:2,53
+// The WebGPU device becomes a pt context on one MI355X (requestDevice), every WGSL dispatch becomes a
+// call into libpt_amd.so through the N-API addon.  Host-side numerics stay in JS doubles and are rounded to
+// f32 exactly where the reference rounds them (Float32Array stores / DataView.setFloat32).
+"use strict"
+const fs = require("fs")
+const zlib = require("zlib")
+const path = require("path")
+
+let native = null
+function addon() {
+    if (!native) native = require(path.join(__dirname, "pt_amd.node"))   // throws if the addon was not built
+    return native
+}
+
+// ---- requestAdapter()/requestDevice() (main.js:3-4) ------------------------------------------------------------
+function requestDevice(deviceId = 0) {
+    const ctx = addon().create(deviceId)
+    return { ctx, destroy() { addon().destroy(ctx) } }
+}
+
+// ---- OBJ text -> padded triangle list + bounds (semantics of parse-obj.js:1-90) ---------------------------------
+// v / f / o records only; indices are 1-based through a sentinel vertex and read like parseInt ("7/2/3" -> 7);
+// polygons are fanned from their first corner; an "o" record starts a fresh vertex list; the bounds cover every
+// v record whether or not a face uses it.  Each corner is padded to four floats with 3.1415.
+function parseObj(text) {
+    const PAD = 3.1415
+    const lo = [1e30, 1e30, 1e30], hi = [-1e30, -1e30, -1e30]
+    const out = []
+    let pool = [1e30, 1e30, 1e30]
+    for (const line of text.split("\n")) {
+        if (line.length <= 1 || !"vfo".includes(line[0])) continue
+        const tok = line.split(/\s+/)
+        if (tok[0] === "v") {
+            for (let k = 0; k < 3; k++) {
+                const c = parseFloat(tok[k + 1])
+                lo[k] = Math.min(lo[k], c); hi[k] = Math.max(hi[k], c)
+                pool.push(c)
+            }
+        } else if (tok[0] === "f") {
+            const corners = tok.slice(1).map(t => parseInt(t)).filter(i => !isNaN(i))
+            const at = i => [pool[3 * i], pool[3 * i + 1], pool[3 * i + 2], PAD]
+            for (let k = 1; k + 1 < corners.length; k++) out.push(...at(corners[0]), ...at(corners[k]), ...at(corners[k + 1]))
+        } else if (tok[0] === "o") {
+            pool = [1e30, 1e30, 1e30]
+        }
+    }
+    return { numTriangles: out.length / 12, triangleArray: out, bounds: { min: lo, max: hi } }
+}
+
+// ---- TRS matrices, column-major 4x4 (semantics of transform-utils.js:45-176) ------------------------------------
+function matMul(a, b) {             // element (r,c) = sum_k a(r,k) b(k,c), accumulated left to right
+    const m = new Array(16)
+    for (let c = 0; c < 4; c++)
+        for (let r = 0; r < 4; r++)
+            m[4 * c + r] = a[r] * b[4 * c] + a[4 + r] * b[4 * c + 1] + a[8 + r] * b[4 * c + 2] + a[12 + r] * b[4 * c + 3]
+    return m
+}
+const translation = p => [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, p[0], p[1], p[2], 1]
+const scaling = s => [s[0], 0, 0, 0, 0, s[1], 0, 0, 0, 0, s[2], 0, 0, 0, 0, 1]
+function axisRotations(a) {
+    const [cx, sx, cy, sy, cz, sz] = [Math.cos(a[0]), Math.sin(a[0]), Math.cos(a[1]), Math.sin(a[1]), Math.cos(a[2]), Math.sin(a[2])]
+    return {
+        x: [1, 0, 0, 0, 0, cx, sx, 0, 0, -sx, cx, 0, 0, 0, 0, 1],
+        y: [cy, 0, -sy, 0, 0, 1, 0, 0, sy, 0, cy, 0, 0, 0, 0, 1],
+        z: [cz, sz, 0, 0, -sz, cz, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1],
+    }
+}
+function computeTransformMatrices(t) {
+    const f = axisRotations(t.rotation), b = axisRotations(t.rotation.map(x => -x))
+    const rot = matMul(f.z, matMul(f.y, f.x)), unrot = matMul(b.x, matMul(b.y, b.z))
+    return {
+        localToWorld: matMul(translation(t.position), matMul(rot, scaling(t.scale))),
+        worldToLocal: matMul(scaling(t.scale.map(s => 1. / s)), matMul(unrot, translation(t.position.map(x => -x)))),
+    }
+}
+function getTransformedBoundingBox(mats, box) {   // box of the 8 mapped corners, in the reference's corner order
+    const m = mats.localToWorld, a = box.min, b = box.max
+    const corners = [[a[0], a[1], a[2]], [b[0], a[1], a[2]], [a[0], b[1], a[2]], [a[0], a[1], b[2]],
+                     [b[0], a[1], b[2]], [b[0], b[1], a[2]], [a[0], b[1], b[2]], [b[0], b[1], b[2]]]
+    const min = [1e30, 1e30, 1e30], max = [-1e30, -1e30, -1e30]
+    for (const p of corners)
+        for (let r = 0; r < 3; r++) {
+            const q = m[r] * p[0] + m[4 + r] * p[1] + m[8 + r] * p[2] + m[12 + r]
+            min[r] = Math.min(min[r], q); max[r] = Math.max(max[r], q)
+        }
+    return { min, max }
+}
+
+// ---- initScene (scene.js) ---------------------------------------------------------------------------------------
+function initScene(device) {
+    const meshes = [], objects = []
+    let built = false
+
+    function registerMesh(mesh) {          // scene.js:518-521; {file: objText} or {triangles, bounds} (generated meshes)
+        const parsed = mesh.file !== undefined ? parseObj(mesh.file)
+            : { numTriangles: mesh.triangles.length / 12, triangleArray: mesh.triangles, bounds: mesh.bounds }
+        const tris = Float32Array.from(parsed.triangleArray)                        // builders.js:164
+        const b6 = Float32Array.from([...parsed.bounds.min, ...parsed.bounds.max])  // aabb-z-idx.js:116-122
+        const handle = addon().meshUpload(device.ctx, tris, b6)
+        meshes.push({ mesh, handle, bounds: parsed.bounds, numTriangles: parsed.numTriangles })
+        return meshes.length - 1
+    }
+    function instanceMesh(meshID, position, rotation, scale, material) {            // scene.js:523-529
+        if (meshID >= meshes.length || meshID < 0) {
+            console.warn(`ERROR in scene::instanceMesh: mesh with ID ${meshID} does not exist`)
+            return
+        }
+        objects.push({ type: "mesh", meshID, material, transform: { position, rotation, scale } })
+    }
+    async function build() {                                                        // scene.js:15-146
+        const words = new ArrayBuffer(160 * Math.max(objects.length, 1))
+        const f = new Float32Array(words), i = new Int32Array(words)
+        objects.forEach((o, k) => {
+            o.transformMatrices = computeTransformMatrices(o.transform)
+            o.bounds = getTransformedBoundingBox(o.transformMatrices, meshes[o.meshID].bounds)
+            f.set(o.transformMatrices.localToWorld, 40 * k); f.set(o.transformMatrices.worldToLocal, 40 * k + 16)
+            f.set(o.bounds.min, 40 * k + 32); f.set(o.bounds.max, 40 * k + 35)
+            i[40 * k + 38] = meshes[o.meshID].handle; i[40 * k + 39] = o.material
+        })
+        addon().sceneBuild(device.ctx, f, objects.length)
+        built = true
+    }
+    const notBuilt = () => { if (!built) console.warn("ERROR in scene::getSceneBindGroupInfo: scene has not been built yet") }
+    const kernels = {   // the scene -> render hand-off (scene.js:13): device buffers instead of WGSL strings + a bind group
+        getSceneBindGroupInfo() { notBuilt(); return built ? addon().sceneInfo(device.ctx) : null },
+        readBuffer(which, out, mesh) { return mesh === undefined ? addon().readBuffer(device.ctx, which, out) : addon().readBuffer(device.ctx, which, out, meshes[mesh].handle) },
+        traceRays(o, d, hitObj, hitTri, hitDist) { addon().traceRays(device.ctx, o, d, hitObj, hitTri, hitDist || null) },
+    }
+    return { registerMesh, instanceMesh, build, kernels }
+}
+
+// ---- initPathTracer (path-tracer.js) ----------------------------------------------------------------------------
+function initPathTracer(params) {
+    const device = params.device, s = params.settings || {}
+    addon().renderInit(device.ctx, {
+        width: params.image.width, height: params.image.height,
+        position: params.camera.position, lookAt: params.camera.lookAt, fov: params.camera.fov,
+        samples: s.samples, numPaths: s.numPaths || 0, slotBase: s.slotBase || 0,
+        ticketBegin: s.ticketBegin || 0, ticketEnd: s.ticketEnd === undefined ? -1 : s.ticketEnd,
+    })
+    async function step() { return addon().renderStep(device.ctx) }                 // path-tracer.js:49-123
+    function getImageBuffer() { return { device, width: params.image.width, height: params.image.height } }   // :125-127
+    async function run(maxSteps = 0, flags = 0) { return addon().renderRun(device.ctx, maxSteps, flags) }     // main.js:61-72 loop
+    function readImage() {
+        const out = new Float32Array(params.image.width * params.image.height * 4)
+        addon().imageRead(device.ctx, out)
+        return out
+    }
+    return { step, getImageBuffer, run, readImage, reset: () => addon().renderReset(device.ctx) }
+}
+
+// ---- initDisplay (display.js): the canvas is a PNG (or raw RGBA8) ------------------------------------------------
+function initDisplay(params) {
+    const { width, height } = params.image
+    function draw() {                                                               // display.js:55-72, 98-113
+        const rgba = new Uint8Array(width * height * 4)
+        addon().tonemap(params.device.ctx, rgba)
+        if (params.canvas) fs.writeFileSync(params.canvas, encodePNG(rgba, width, height))
+        return rgba
+    }
+    return { draw }
+}
+
+function encodePNG(rgba, w, h) {
+    const crcTable = new Int32Array(256).map((_, n) => { let c = n; for (let k = 0; k < 8; k++) c = c & 1 ? 0xedb88320 ^ (c >>> 1) : c >>> 1; return c })
+    const crc = buf => { let c = -1; for (const b of buf) c = crcTable[(c ^ b) & 255] ^ (c >>> 8); return (c ^ -1) >>> 0 }
+    const chunk = (tag, data) => {
+        const body = Buffer.concat([Buffer.from(tag, "ascii"), data]), len = Buffer.alloc(4), sum = Buffer.alloc(4)
+        len.writeUInt32BE(data.length); sum.writeUInt32BE(crc(body))
+        return Buffer.concat([len, body, sum])
+    }
+    const raw = Buffer.alloc((w * 4 + 1) * h)
+    for (let y = 0; y < h; y++) Buffer.from(rgba.buffer, rgba.byteOffset + y * w * 4, w * 4).copy(raw, y * (w * 4 + 1) + 1)
+    const ihdr = Buffer.alloc(13); ihdr.writeUInt32BE(w, 0); ihdr.writeUInt32BE(h, 4); ihdr.set([8, 6, 0, 0, 0], 8)
+    return Buffer.concat([Buffer.from([137, 80, 78, 71, 13, 10, 26, 10]), chunk("IHDR", ihdr), chunk("IDAT", zlib.deflateSync(raw)), chunk("IEND", Buffer.alloc(0))])
+}
+
+module.exports = { requestDevice, initScene, initPathTracer, initDisplay, parseObj, computeTransformMatrices, getTransformedBoundingBox, encodePNG }

@@ -1,0 +1,34 @@
+"""Multi-GPU host logic: one process per GPU, samples-per-pixel split, one sum-reduce.
+
+The path shards without any data-path collective: every GPU holds a full scene replica and a private
+W*H*vec4f accumulation buffer, works on its own range of pixel tickets (logic.js:155-184) with its own
+RNG streams (global slot index = rank * NUM_PATHS + slot, logic.js:77), and the buffers -- sums of radiance
+plus sample counts, logic.js:146-149 -- are added once at the end (RCCL reduce over xGMI; gloo on CPU)."""
+
+SAMPLES_PER_TICKET = 8   # logic.js:6
+
+
+def tickets_for(width, height, spp):
+    return (width * height * spp + SAMPLES_PER_TICKET - 1) // SAMPLES_PER_TICKET     # logic.js:177
+
+
+def weak_share(rank, world, width, height, spp_per_gpu, num_paths):
+    """Every GPU renders spp_per_gpu; the node accumulates world * spp_per_gpu samples per pixel."""
+    t = tickets_for(width, height, spp_per_gpu)
+    return {"samples": spp_per_gpu * world, "numPaths": num_paths, "slotBase": rank * num_paths,
+            "ticketBegin": rank * t, "ticketEnd": (rank + 1) * t}
+
+
+def strong_share(rank, world, width, height, spp_total, num_paths):
+    """A fixed spp_total is split evenly: GPU g takes tickets [g*T/G, (g+1)*T/G)."""
+    t = tickets_for(width, height, spp_total)
+    return {"samples": spp_total, "numPaths": num_paths, "slotBase": rank * num_paths,
+            "ticketBegin": rank * t // world, "ticketEnd": (rank + 1) * t // world}
+
+
+def reduce_image(image_tensor, dst=0):
+    """Sum the per-rank accumulation buffers onto rank dst (backend nccl = RCCL on ROCm; gloo in CPU tests)."""
+    import torch.distributed as dist
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.reduce(image_tensor, dst=dst, op=dist.ReduceOp.SUM)
+    return image_tensor

@@ -124,8 +124,32 @@ def bunny_scale_scene(level=6, seed=3):
             "camera": {"position": [3.2, 3.2, 2.4], "lookAt": [0, 0, 1.1], "fov": 28}}
 
 
+def _cached(key, make):
+    """Large generated meshes are kept as .npz under $PT_SCENE_CACHE (default /tmp/pt_scene_cache) between runs."""
+    import os
+    d = os.environ.get("PT_SCENE_CACHE", "/tmp/pt_scene_cache")
+    f = os.path.join(d, key + ".npz")
+    if os.path.exists(f):
+        z = np.load(f)
+        return {"triangles": z["triangles"], "bounds": {"min": z["bmin"].tolist(), "max": z["bmax"].tolist()}}
+    m = make()
+    try:
+        os.makedirs(d, exist_ok=True)
+        np.savez(f + ".tmp.npz", triangles=m["triangles"], bmin=np.asarray(m["bounds"]["min"]), bmax=np.asarray(m["bounds"]["max"]))
+        os.replace(f + ".tmp.npz", f)
+    except OSError:
+        pass
+    return m
+
+
 def displaced_grid(nx=2236, ny=2236, seed=4, extent=20.0, height=1.5):
     """C4: nx*ny quads = 2*nx*ny triangles (2236^2 -> 9,999,392) over [-extent/2, extent/2]^2, z = seeded value noise."""
+    if nx * ny >= 250_000:
+        return _cached(f"grid_{nx}_{ny}_{seed}_{extent}_{height}", lambda: _displaced_grid(nx, ny, seed, extent, height))
+    return _displaced_grid(nx, ny, seed, extent, height)
+
+
+def _displaced_grid(nx, ny, seed, extent, height):
     xs = np.linspace(-extent / 2, extent / 2, nx + 1); ys = np.linspace(-extent / 2, extent / 2, ny + 1)
     X, Y = np.meshgrid(xs, ys, indexing="xy")
     P = np.stack([X.reshape(-1), Y.reshape(-1), np.zeros(X.size)], axis=1)

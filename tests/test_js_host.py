@@ -1,0 +1,76 @@
+"""The Node.js host (path-tracer_amd/js): host logic against the reference's golden vectors, addon loading,
+and -- on the GPU box -- the same render through node + N-API as through the Python host."""
+import json
+import math
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+JS = os.path.join(ROOT, "path-tracer_amd", "js")
+NODE = shutil.which("node")
+needs_node = pytest.mark.skipif(NODE is None, reason="node is not installed")
+
+
+@needs_node
+def test_js_host_logic_matches_reference_fixtures():
+    r = subprocess.run([NODE, "check-host.js"], cwd=JS, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+@needs_node
+def test_addon_loads_and_exports_the_boundary():
+    if not os.path.exists(os.path.join(JS, "pt_amd.node")):
+        pytest.skip("addon not built (run __graft_entry__.build())")
+    code = "const a=require('./pt_amd.node');console.log(JSON.stringify(Object.keys(a).sort()))"
+    r = subprocess.run([NODE, "-e", code], cwd=JS, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    names = json.loads(r.stdout)
+    for n in ("create", "destroy", "meshUpload", "sceneBuild", "renderInit", "renderStep", "renderRun", "imageRead", "tonemap", "traceRays"):
+        assert n in names
+
+
+@needs_node
+def test_addon_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available() or not os.path.exists(os.path.join(JS, "pt_amd.node")):
+        pytest.skip("only meaningful on a box without a GPU")
+    r = subprocess.run([NODE, "main.js", "--width", "8", "--height", "8"], cwd=JS, capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "no HIP device" in r.stderr
+
+
+BOX = "\n".join(["v -0.5 -0.5 0", "v 0.5 -0.5 0", "v 0.5 0.5 0", "v -0.5 0.5 0", "v -0.5 -0.5 1.4", "v 0.5 -0.5 1.4", "v 0.5 0.5 1.4",
+                 "v -0.5 0.5 1.4", "f 1 4 3 2", "f 5 6 7 8", "f 1 2 6 5", "f 3 4 8 7", "f 1 5 8 4", "f 2 3 7 6"])
+
+
+@needs_node
+@pytest.mark.gpu
+def test_node_render_equals_python_host_render(pta, device):
+    """main.js (JS host -> N-API -> C ABI) and the Python host drive the same library: identical frames."""
+    w, h, spp, paths, grid = 64, 48, 8, 3000, 3
+    r = subprocess.run([NODE, "main.js", "--width", str(w), "--height", str(h), "--samples", str(spp), "--paths", str(paths),
+                        "--grid", str(grid), "--json", "--out", "/tmp/node_frame.png"], cwd=JS, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    scene = pta.init_scene(device)
+    box = scene.register_mesh({"file": BOX}); floor = scene.register_mesh({"file": pta.scenes.FLOOR_OBJ})
+    lcg = 12345
+    for i in range(grid * grid):
+        lcg = (lcg * 1664525 + 1013904223) & 0xFFFFFFFF
+        scene.instance_mesh(box, [(i % grid) * 2, (i // grid) * 2, -1.3], [0, 0, lcg / 4294967296 * math.pi * 2.0], [1, 1, 1], 1)
+    scene.instance_mesh(floor, [10, 10, -1.3], [0, 0, 0], [5, 5, 5], 0)
+    scene.build()
+    pt = pta.init_path_tracer({"device": device, "scene": scene, "image": {"width": w, "height": h},
+                               "camera": {"lookAt": [10, 10, 0], "position": [15, 15, 5], "fov": 60}, "settings": {"samples": spp, "numPaths": paths}})
+    rs = pt.run()
+    img = pt.read_image()
+    assert rep["steps"] == rs.steps and rep["rays"] == rs.total_rays
+    assert rep["sampleCount"] == w * h * spp == img[..., 3].sum()
+    assert rep["info"]["nTris"] == 14 and rep["info"]["nObjects"] == grid * grid + 1
+    np.testing.assert_allclose(rep["radianceSum"], img[..., 0].astype(np.float64).sum(), rtol=1e-12)   # spp = 8: frames are bit-identical
+    disp = pta.init_display({"device": device, "image": {"buffer": pt.get_image_buffer(), "width": w, "height": h}})
+    assert rep["firstPixel"] == disp.draw()[0, 0].tolist()
+    assert os.path.getsize("/tmp/node_frame.png") > 100
