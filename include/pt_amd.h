@@ -139,6 +139,15 @@ int pt_path_state_read(pt_ctx* ctx, const char* field, void* out, size_t bytes);
 /* stage-2 queues of the last step: which = 0 camera_queue, 1 material_queue. *n_io in: capacity, out: count */
 int pt_queue_read(pt_ctx* ctx, int which, int32_t* out, int64_t* n_io);
 
+/* ---- measurement hooks (no reference counterpart; used by tools/ and bench.py only) ---- */
+/* The extend stage exists in several variants that differ in ray-to-lane mapping and stack placement, never in
+ * results.  pt_extend_variants returns how many there are and copies the name of `variant`. */
+int pt_extend_variants(pt_ctx* ctx, int variant, char* name_out, size_t name_cap);
+int pt_set_extend_variant(pt_ctx* ctx, int variant);      /* also: environment PT_EXTEND_VARIANT at pt_create */
+/* Re-run the extend kernel `reps` times on the ray queue of the last step (idempotent) and report its mean
+ * duration in microseconds: A/B of variants on identical work inside one process. */
+int pt_extend_replay(pt_ctx* ctx, int variant, int reps, double* avg_us);
+
 /* ---- display (scripts/display) ---- */
 /* replaces: initDisplay().draw() fragment shader (display.js:98-113) + canvas unorm8 store.
  * image_dev NULL -> the ctx's image.  rgba8: W*H*4 bytes (host), row 0 = top. */

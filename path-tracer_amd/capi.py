@@ -63,6 +63,9 @@ SIGNATURES = {
     "pt_image_dev_ptr": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "pt_path_state_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),
     "pt_queue_read": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int64)]),
+    "pt_extend_variants": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]),
+    "pt_set_extend_variant": (C.c_int, [C.c_void_p, C.c_int]),
+    "pt_extend_replay": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "pt_tonemap_rgba8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
 }
 

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -28,7 +29,7 @@ struct Mesh {
 }  // namespace
 
 struct pt_ctx {
-    int device = 0; hipStream_t stream = nullptr; bool own_stream = false; std::string err;
+    int device = 0; int n_cus = 256; int extend_variant = 0; hipStream_t stream = nullptr; bool own_stream = false; std::string err;
     std::vector<Mesh> meshes;
     // scene
     bool scene_built = false; int64_t n_tris = 0; int n_objects = 0; int n_meshes_used = 0;
@@ -136,7 +137,7 @@ void enqueue_step(pt_ctx* c, int count_visits, hipEvent_t ev0, hipEvent_t ev1) {
     ptk_generate(c->ps, c->rc, c->d_hdr, c->d_cam_q, c->stream);
     ptk_shade(c->ps, c->rc, sv, c->d_hdr, c->d_mat_q, c->stream);
     if (ev0) (void)hipEventRecord(ev0, c->stream);
-    ptk_extend_queue(c->ps, c->rc, sv, c->d_hdr, c->d_cam_q, c->d_mat_q, c->d_spill, count_visits, c->stream);
+    ptk_extend_queue(c->ps, c->rc, sv, c->d_hdr, c->d_cam_q, c->d_mat_q, c->d_spill, count_visits, c->extend_variant, c->n_cus, c->stream);
     if (ev1) (void)hipEventRecord(ev1, c->stream);
     c->step++;
 }
@@ -169,6 +170,10 @@ int pt_create(int device_id, pt_ctx** out) {
         delete c; return fail(nullptr, PT_ERR_HIP, "pt_create: hipSetDevice/hipStreamCreate failed");
     }
     c->own_stream = true;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount;
+    c->extend_variant = 2;   // queue mapping, 64-thread workgroups, 16 LDS stack entries (tools/extend_ab.py: fastest on every scene)
+    if (const char* v = getenv("PT_EXTEND_VARIANT")) c->extend_variant = atoi(v);
     *out = c;
     return PT_OK;
 }
@@ -473,6 +478,39 @@ int pt_queue_read(pt_ctx* c, int which, int32_t* out, int64_t* n_io) {
     if (cnt > *n_io) return fail(c, PT_ERR_ARG, "pt_queue_read: buffer too small");
     *n_io = cnt;
     return cnt ? read_back(c, out, which == 0 ? c->d_cam_q : c->d_mat_q, (size_t)cnt * 4) : PT_OK;
+}
+
+// ------------------------------------------------------------------------------- measurement hooks
+int pt_extend_variants(pt_ctx* c, int variant, char* name_out, size_t name_cap) {
+    if (name_out && name_cap) { strncpy(name_out, ptk_extend_variant_name(variant), name_cap - 1); name_out[name_cap - 1] = 0; }
+    return ptk_extend_num_variants();
+}
+
+int pt_set_extend_variant(pt_ctx* c, int variant) {
+    if (!c || variant < 0 || variant >= ptk_extend_num_variants()) return fail(c, PT_ERR_ARG, "pt_set_extend_variant: no such variant");
+    c->extend_variant = variant;
+    return PT_OK;
+}
+
+int pt_extend_replay(pt_ctx* c, int variant, int reps, double* avg_us) {
+    if (!c || !avg_us || reps < 1 || variant < 0 || variant >= ptk_extend_num_variants()) return fail(c, PT_ERR_ARG, "pt_extend_replay: bad argument");
+    if (!c->render_ready || c->step == 0) return fail(c, PT_ERR_STATE, "pt_extend_replay: take at least one step first");
+    HIPOK(c, hipSetDevice(c->device));
+    hipEvent_t e0, e1; HIPOK(c, hipEventCreate(&e0)); HIPOK(c, hipEventCreate(&e1));
+    SceneView sv = scene_view(c);
+    double total_ms = 0;
+    for (int i = 0; i < reps; i++) {   // the kernel only reads path_o/path_d and rewrites the same hit_obj/hit_tri: idempotent
+        HIPOK(c, hipMemsetAsync(&c->d_hdr->work_counter, 0, 4, c->stream));
+        HIPOK(c, hipEventRecord(e0, c->stream));
+        ptk_extend_queue(c->ps, c->rc, sv, c->d_hdr, c->d_cam_q, c->d_mat_q, c->d_spill, 0, variant, c->n_cus, c->stream);
+        HIPOK(c, hipEventRecord(e1, c->stream));
+        HIPOK(c, hipEventSynchronize(e1));
+        float ms = 0; HIPOK(c, hipEventElapsedTime(&ms, e0, e1)); total_ms += ms;
+    }
+    HIPOK(c, hipGetLastError());
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *avg_us = total_ms * 1e3 / reps;
+    return PT_OK;
 }
 
 // ---------------------------------------------------------------------------------------- display

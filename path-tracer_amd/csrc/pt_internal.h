@@ -46,7 +46,7 @@ struct StepHeader {
     int64_t  total_samples;
     unsigned long long overflow; // rays stopped by the stack / iteration guards
     unsigned long long visits[4];// n_inner, n_leaf, n_enter, n_leave (counting variant only)
-    int32_t  step_index, pad;
+    int32_t  step_index, work_counter;   // work_counter: next ray-queue entry for the persistent extend kernel
 };
 
 struct RenderConst {
@@ -79,7 +79,9 @@ void ptk_shade(const PathState& ps, const RenderConst& rc, const SceneView& sc, 
                const int32_t* mat_q, hipStream_t s);
 // Extend over the step's ray queue (camera ++ material).  count != 0 selects the visit-counting variant.
 void ptk_extend_queue(const PathState& ps, const RenderConst& rc, const SceneView& sc, StepHeader* hdr,
-                      const int32_t* cam_q, const int32_t* mat_q, int32_t* spill, int count, hipStream_t s);
+                      const int32_t* cam_q, const int32_t* mat_q, int32_t* spill, int count, int variant, int n_cus, hipStream_t s);
+int ptk_extend_num_variants();
+const char* ptk_extend_variant_name(int v);
 // Extend over n caller rays (o4/d4: float4 per ray).  counts4 (int4 per ray) may be null.
 void ptk_extend_direct(const SceneView& sc, const float4* o4, const float4* d4, int n, int32_t* hit_obj,
                        int32_t* hit_tri, float* hit_dist, int4* counts4, int32_t* spill, StepHeader* hdr, hipStream_t s);

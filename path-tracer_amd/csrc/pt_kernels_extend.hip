@@ -1,0 +1,291 @@
+// pt_kernels_extend.hip -- the extend stage on gfx950: closest hit over the two-level LBVH
+// (ray-trace.js:53-69 driving intersect_bvh, scene.js:313-515).
+//
+// One ray per lane.  Every variant below performs the reference's traversal in the reference's order
+// (near child first, ties to the right child, single stack shared by TLAS and BLAS, hit_dist carried
+// through the object-space round trips), so hit indices, hit distances and per-ray visit counts do not
+// depend on the variant; variants differ only in how rays are mapped to lanes and where the stack lives.
+//
+// Stack: the first LDS_N entries of a lane's stack live in LDS as [entry][thread] (bank = thread & 31
+// whatever the entry, lanes l / l+32 are served in different LDS cycles: divergent depths never
+// conflict); deeper entries go to an HBM spill laid out [entry][slot] so that equal depths coalesce.
+#include "pt_internal.h"
+#include "pt_math.cuh"
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int rank_below(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+}
+
+template <int LDS_N, int BLOCK>
+struct Stack {
+    int* lds;            // &s_stack[0][thread]
+    int32_t* spill;      // &spill[0][slot]
+    int64_t stride;      // slots per spill entry
+    __device__ __forceinline__ void put(int sp, int v) const {
+        if (sp < LDS_N) lds[sp * BLOCK] = v; else spill[(int64_t)(sp - LDS_N) * stride] = v;
+    }
+    __device__ __forceinline__ int get(int sp) const {
+        return sp < 0 ? 0 : (sp < LDS_N ? lds[sp * BLOCK] : spill[(int64_t)(sp - LDS_N) * stride]);
+    }
+};
+
+struct Ray {
+    f3 o, d, id;                 // origin, direction, 1/direction in the current space
+    float hit_dist; int hit_obj, hit_tri;
+    int sp, node, obj, switch_pt, iter;
+    int n_inner, n_leaf, n_enter, n_leave, overflow;
+};
+
+__device__ __forceinline__ void ray_init(Ray& r, f3 o, f3 d) {
+    r.o = o; r.d = d; r.id = rcp3(d);
+    r.hit_dist = 1e6f; r.hit_obj = -1; r.hit_tri = -1;                       // scene.js:317-319
+    r.sp = 0; r.node = 0; r.obj = -1; r.switch_pt = -1; r.iter = 0;        // scene.js:321-324
+    r.n_inner = r.n_leaf = r.n_enter = r.n_leave = 0; r.overflow = 0;
+}
+
+// scene.js:508-515 with 1/d hoisted (it only changes when the ray changes space)
+__device__ __forceinline__ float slab(f3 low, f3 high, f3 o, f3 id) {
+    f3 f = (high - o) * id, n = (low - o) * id;
+    f3 tmax = max3(f, n), tmin = min3(f, n);
+    float t0 = fmax_(tmin.x, fmax_(tmin.y, tmin.z));
+    float t1 = fmin_(tmax.x, fmin_(tmax.y, tmax.z));
+    return (t1 >= t0) ? ((t1 < 0.0f) ? -1e30f : t0) : -1e30f;
+}
+// scene.js:478-506
+__device__ __forceinline__ float tri_hit(f3 o, f3 d, float4 a, float4 b, float4 c) {
+    f3 v0 = F3(a), v0v1 = F3(b) - v0, v0v2 = F3(c) - v0;
+    f3 pvec = cross3(d, v0v2);
+    float det = dot3(v0v1, pvec);
+    if (__builtin_fabsf(det) < 1e-10f) return -1.0f;
+    float i_det = 1.0f / det;
+    f3 tvec = o - v0;
+    float u = dot3(tvec, pvec) * i_det;
+    if (u < 0.0f || u > 1.0f) return -1.0f;
+    f3 qvec = cross3(tvec, v0v1);
+    float v = dot3(d, qvec) * i_det;
+    if (v < 0.0f || u + v > 1.0f) return -1.0f;
+    return dot3(v0v2, qvec) * i_det;
+}
+// scene.js:333-350 / :364-379: map o and the point o + d*hit_dist, renormalise d, recompute hit_dist
+__device__ __forceinline__ void switch_space(float4 r0, float4 r1, float4 r2, Ray& r) {
+    f3 hit_pos = r.o + r.d * r.hit_dist;
+    f3 new_o = xform(r0, r1, r2, r.o, 1.0f), new_h = xform(r0, r1, r2, hit_pos, 1.0f);
+    f3 nd = new_h - new_o;
+    r.hit_dist = length3(nd);
+    r.d = nd / r.hit_dist;
+    r.o = new_o;
+    r.id = rcp3(r.d);
+}
+
+// One trip through the reference's while loop (scene.js:328-440).  Returns false when the loop ends.
+template <bool COUNT, class STK>
+__device__ __forceinline__ bool trav_step(const SceneView& sc, Ray& r, const STK& stk) {
+    if (r.sp < 0) return false;
+    if (++r.iter > PT_MAX_ITERS) { r.overflow = 1; return false; }
+    if (r.sp < r.switch_pt) {                                   // :330-355 leaving the object
+        const float4* ob = sc.objects + 8 * (int64_t)r.obj;
+        switch_space(ob[0], ob[1], ob[2], r);
+        r.switch_pt = -1; r.obj = -1;
+        if (COUNT) r.n_leave++;
+    }
+    if (r.node < 0) {
+        if (r.obj < 0) {                                        // :357-379 entering an object
+            r.obj = -(r.node + 1);
+            const float4* ob = sc.objects + 8 * (int64_t)r.obj;
+            r.node = __float_as_int(ob[3].x); r.switch_pt = r.sp;
+            switch_space(ob[4], ob[5], ob[6], r);
+            if (COUNT) r.n_enter++;
+        } else {                                                // :380-391 triangle
+            int t = -(r.node + 1);
+            const float4* tr = sc.tris + 3 * (int64_t)t;
+            float dist = tri_hit(r.o, r.d, tr[0], tr[1], tr[2]);
+            if (dist > 0.0f && dist < r.hit_dist) { r.hit_dist = dist; r.hit_tri = t; r.hit_obj = r.obj; }
+            if (COUNT) r.n_leaf++;
+            r.sp -= 1; r.node = stk.get(r.sp);
+        }
+    } else {                                                    // :392-439 inner node
+        const float4* nd = (r.obj < 0 ? sc.tlas : sc.blas) + 4 * (int64_t)r.node;
+        float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+        if (COUNT) r.n_inner++;
+        float l_dist = slab(F3(q0), F3(q1), r.o, r.id), r_dist = slab(F3(q2), F3(q3), r.o, r.id);
+        bool l_valid = l_dist != -1e30f && l_dist < r.hit_dist;
+        bool r_valid = r_dist != -1e30f && r_dist < r.hit_dist;
+        int l_child = __float_as_int(q0.w), r_child = __float_as_int(q2.w);
+        if (l_valid && r_valid) {
+            bool l_first = l_dist < r_dist;
+            if (r.sp >= PT_STACK_SIZE) { r.overflow = 1; return false; }
+            stk.put(r.sp, l_first ? r_child : l_child);
+            r.sp += 1; r.node = l_first ? l_child : r_child;
+        } else if (l_valid) r.node = l_child;
+        else if (r_valid)   r.node = r_child;
+        else { r.sp -= 1; r.node = stk.get(r.sp); }
+    }
+    return r.sp >= 0;
+}
+// scene.js:442-466: a ray that ends inside an object is mapped back to world space
+template <bool COUNT>
+__device__ __forceinline__ void trav_finish(const SceneView& sc, Ray& r) {
+    if (r.obj >= 0) {
+        const float4* ob = sc.objects + 8 * (int64_t)r.obj;
+        switch_space(ob[0], ob[1], ob[2], r);
+        if (COUNT) r.n_leave++;
+    }
+}
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    return v;
+}
+// overflow count (always) and visit counts (counting variant) -> StepHeader, one atomic per wave and counter
+template <bool COUNT>
+__device__ __forceinline__ void publish(unsigned long long ov, unsigned long long a, unsigned long long b, unsigned long long c,
+                                        unsigned long long e, StepHeader* hdr) {
+    if (__any(ov != 0)) { ov = wave_sum(ov); if (lane_id() == 0) atomicAdd(&hdr->overflow, ov); }
+    if (COUNT) {
+        a = wave_sum(a); b = wave_sum(b); c = wave_sum(c); e = wave_sum(e);
+        if (lane_id() == 0) { atomicAdd(&hdr->visits[0], a); atomicAdd(&hdr->visits[1], b); atomicAdd(&hdr->visits[2], c); atomicAdd(&hdr->visits[3], e); }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// Variant A: one launch thread per queue entry (the reference's mapping, ray-trace.js:55-60)
+// --------------------------------------------------------------------------------------------
+template <int LDS_N, int BLOCK, bool COUNT>
+__global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView sc, StepHeader* hdr, const int32_t* __restrict__ cam_q,
+                                                        const int32_t* __restrict__ mat_q, int32_t* spill, int64_t spill_stride) {
+    __shared__ int s_stack[LDS_N * BLOCK];
+    int q = blockIdx.x * BLOCK + threadIdx.x;
+    int n_cam = hdr->n_camera, n_rays = n_cam + hdr->n_material;
+    Ray r; ray_init(r, F3(0, 0, 1), F3(0, 0, 1));
+    if (q < n_rays) {
+        int path = q < n_cam ? cam_q[q] : mat_q[q - n_cam];
+        ray_init(r, F3(ps.path_o[path]), F3(ps.path_d[path]));
+        Stack<LDS_N, BLOCK> stk{s_stack + threadIdx.x, spill + q, spill_stride};
+        while (trav_step<COUNT>(sc, r, stk)) {}
+        trav_finish<COUNT>(sc, r);
+        ps.hit_obj[path] = r.hit_obj; ps.hit_tri[path] = r.hit_tri;
+    }
+    publish<COUNT>(r.overflow, r.n_inner, r.n_leaf, r.n_enter, r.n_leave, hdr);
+}
+
+// --------------------------------------------------------------------------------------------
+// Variant B: persistent waves with lane refill.  The grid is sized to the machine, not to the queue.
+// The queue is cut into one contiguous share per wave (no atomics: one device-wide counter saturates at
+// ~88 dequeues/us, far below the rate short rays need); inside its share a wave hands the next ray to any
+// lane whose ray has finished, so short rays do not leave lanes idle while the longest ray of the wave is
+// still walking.  Exit: a wave leaves once its share is used up and all its lanes are idle.
+// --------------------------------------------------------------------------------------------
+template <int LDS_N, int BLOCK, bool COUNT>
+__global__ __launch_bounds__(BLOCK) void k_extend_persist(PathState ps, SceneView sc, StepHeader* hdr, const int32_t* __restrict__ cam_q,
+                                                          const int32_t* __restrict__ mat_q, int32_t* spill, int64_t spill_stride,
+                                                          int refill_below) {
+    __shared__ int s_stack[LDS_N * BLOCK];
+    const int n_cam = hdr->n_camera, n_rays = n_cam + hdr->n_material;
+    const int slot = blockIdx.x * BLOCK + threadIdx.x;
+    const int n_waves = gridDim.x * (BLOCK / 64), wave = slot >> 6;
+    const int share = ((n_rays + n_waves - 1) / n_waves + 63) & ~63;      // whole batches of 64
+    int next = min(wave * share, n_rays); const int end = min(next + share, n_rays);
+    Stack<LDS_N, BLOCK> stk{s_stack + threadIdx.x, spill + slot, spill_stride};
+    Ray r; ray_init(r, F3(0, 0, 1), F3(0, 0, 1));
+    bool busy = false; int path = 0;
+    unsigned long long ov = 0, ca = 0, cb = 0, cc = 0, ce = 0;
+    for (;;) {
+        unsigned long long idle = __ballot(!busy);
+        int n_idle = __popcll(idle);
+        if (next < end && n_idle > 64 - refill_below) {          // fewer than refill_below lanes busy: hand out rays
+            if (!busy) {
+                int q = next + rank_below(idle);
+                if (q < end) {
+                    path = q < n_cam ? cam_q[q] : mat_q[q - n_cam];
+                    ray_init(r, F3(ps.path_o[path]), F3(ps.path_d[path]));
+                    busy = true;
+                }
+            }
+            next += n_idle;                                      // wave-uniform
+            idle = __ballot(!busy); n_idle = __popcll(idle);
+        }
+        if (n_idle == 64) break;                                 // share used up and every lane idle
+#pragma unroll 1
+        for (int k = 0; k < 4; k++) {                            // a few trips between refill checks
+            if (busy && !trav_step<COUNT>(sc, r, stk)) {
+                trav_finish<COUNT>(sc, r);
+                ps.hit_obj[path] = r.hit_obj; ps.hit_tri[path] = r.hit_tri;
+                ov += r.overflow; ca += r.n_inner; cb += r.n_leaf; cc += r.n_enter; ce += r.n_leave;
+                busy = false;
+            }
+        }
+    }
+    publish<COUNT>(ov, ca, cb, cc, ce, hdr);
+}
+
+// --------------------------------------------------------------------------------------------
+// Test hook: caller-supplied rays, always counting (pt_trace_rays)
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PT_BLOCK) void k_extend_direct(SceneView sc, const float4* __restrict__ o4, const float4* __restrict__ d4, int n,
+                                                            int32_t* __restrict__ hit_obj, int32_t* __restrict__ hit_tri,
+                                                            float* __restrict__ hit_dist, int4* __restrict__ counts4, int32_t* spill,
+                                                            int64_t spill_stride, StepHeader* hdr) {
+    __shared__ int s_stack[PT_LDS_STACK * PT_BLOCK];
+    int q = blockIdx.x * PT_BLOCK + threadIdx.x;
+    Ray r; ray_init(r, F3(0, 0, 1), F3(0, 0, 1));
+    if (q < n) {
+        ray_init(r, F3(o4[q]), F3(d4[q]));
+        Stack<PT_LDS_STACK, PT_BLOCK> stk{s_stack + threadIdx.x, spill + q, spill_stride};
+        while (trav_step<true>(sc, r, stk)) {}
+        trav_finish<true>(sc, r);
+        hit_obj[q] = r.hit_obj; hit_tri[q] = r.hit_tri; hit_dist[q] = r.hit_dist;
+        if (counts4) counts4[q] = make_int4(r.n_inner, r.n_leaf, r.n_enter, r.n_leave);
+    }
+    publish<false>(r.overflow, 0, 0, 0, 0, hdr);
+}
+
+// ---- launchers -------------------------------------------------------------------------------
+static int64_t pad_to(int64_t n, int64_t m) { return (n + m - 1) / m * m; }
+// The spill is sized for the smallest LDS share any variant uses (16 entries) and the largest slot count.
+size_t ptk_spill_ints(int64_t n_rays) { return (size_t)pad_to(n_rays, 256) * (PT_STACK_SIZE - 16); }
+
+template <int LDS_N, int BLOCK>
+static void launch_queue(const PathState& ps, int num_paths, const SceneView& sc, StepHeader* hdr, const int32_t* cam_q,
+                         const int32_t* mat_q, int32_t* spill, int count, hipStream_t s) {
+    int64_t stride = pad_to(num_paths, 256);
+    dim3 grid((unsigned)((num_paths + BLOCK - 1) / BLOCK));
+    if (count) hipLaunchKernelGGL((k_extend_queue<LDS_N, BLOCK, true>), grid, dim3(BLOCK), 0, s, ps, sc, hdr, cam_q, mat_q, spill, stride);
+    else       hipLaunchKernelGGL((k_extend_queue<LDS_N, BLOCK, false>), grid, dim3(BLOCK), 0, s, ps, sc, hdr, cam_q, mat_q, spill, stride);
+}
+template <int LDS_N, int BLOCK>
+static void launch_persist(const PathState& ps, int num_paths, const SceneView& sc, StepHeader* hdr, const int32_t* cam_q,
+                           const int32_t* mat_q, int32_t* spill, int count, int n_cus, int refill_below, int persist_div, hipStream_t s) {
+    int64_t stride = pad_to(num_paths, 256);
+    int64_t want = (num_paths + BLOCK - 1) / BLOCK, resident = (int64_t)n_cus * (2048 / BLOCK) / (persist_div > 0 ? persist_div : 1);   // 32 waves per CU
+    dim3 grid((unsigned)(want < resident ? want : resident));
+    if (count) hipLaunchKernelGGL((k_extend_persist<LDS_N, BLOCK, true>), grid, dim3(BLOCK), 0, s, ps, sc, hdr, cam_q, mat_q, spill, stride, refill_below);
+    else       hipLaunchKernelGGL((k_extend_persist<LDS_N, BLOCK, false>), grid, dim3(BLOCK), 0, s, ps, sc, hdr, cam_q, mat_q, spill, stride, refill_below);
+}
+
+int ptk_extend_num_variants() { return 8; }
+const char* ptk_extend_variant_name(int v) {
+    static const char* names[] = {"queue b256 lds24", "queue b256 lds16", "queue b64 lds16", "persist b64 lds16 refill<64",
+                                  "persist b64 lds16 refill<48", "persist b64 lds16 refill<32", "persist b64 lds16 refill<48 half grid", "queue b64 lds24"};
+    return (v >= 0 && v < 8) ? names[v] : "?";
+}
+void ptk_extend_queue(const PathState& ps, const RenderConst& rc, const SceneView& sc, StepHeader* hdr, const int32_t* cam_q,
+                      const int32_t* mat_q, int32_t* spill, int count, int variant, int n_cus, hipStream_t s) {
+    int np = rc.num_paths;
+    switch (variant) {
+        default:
+        case 0: launch_queue<24, 256>(ps, np, sc, hdr, cam_q, mat_q, spill, count, s); break;
+        case 1: launch_queue<16, 256>(ps, np, sc, hdr, cam_q, mat_q, spill, count, s); break;
+        case 2: launch_queue<16, 64>(ps, np, sc, hdr, cam_q, mat_q, spill, count, s); break;
+        case 3: launch_persist<16, 64>(ps, np, sc, hdr, cam_q, mat_q, spill, count, n_cus, 64, 1, s); break;
+        case 4: launch_persist<16, 64>(ps, np, sc, hdr, cam_q, mat_q, spill, count, n_cus, 48, 1, s); break;
+        case 5: launch_persist<16, 64>(ps, np, sc, hdr, cam_q, mat_q, spill, count, n_cus, 32, 1, s); break;
+        case 6: launch_persist<16, 64>(ps, np, sc, hdr, cam_q, mat_q, spill, count, n_cus, 48, 2, s); break;
+        case 7: launch_queue<24, 64>(ps, np, sc, hdr, cam_q, mat_q, spill, count, s); break;
+    }
+}
+void ptk_extend_direct(const SceneView& sc, const float4* o4, const float4* d4, int n, int32_t* hit_obj, int32_t* hit_tri,
+                       float* hit_dist, int4* counts4, int32_t* spill, StepHeader* hdr, hipStream_t s) {
+    hipLaunchKernelGGL(k_extend_direct, dim3((unsigned)((n + PT_BLOCK - 1) / PT_BLOCK)), dim3(PT_BLOCK), 0, s, sc, o4, d4, n, hit_obj,
+                       hit_tri, hit_dist, counts4, spill, pad_to(n, 256), hdr);
+}

@@ -121,6 +121,7 @@ __global__ __launch_bounds__(1024) void k_scan(const int4* __restrict__ blk_coun
         hdr->total_samples += tot.w;
         if (tot.x + tot.y == 0 && hdr->first_empty_step < 0) hdr->first_empty_step = hdr->step_index;
         hdr->step_index += 1;
+        hdr->work_counter = 0;
     }
 }
 
@@ -230,162 +231,6 @@ __global__ __launch_bounds__(PT_BLOCK) void k_shade(PathState ps, RenderConst rc
 }
 
 // ============================================================================================
-// extend (ray-trace.js:53-69; scene.js:313-515 intersect_bvh)
-// ============================================================================================
-// One ray per lane.  Traversal state lives in VGPRs; the traversal stack's first PT_LDS_STACK
-// entries live in LDS as [entry][thread] (bank = thread & 31 whatever the entry, and lanes l / l+32
-// are served in different LDS cycles, so divergent stack depths never conflict); deeper entries go
-// to an HBM spill laid out [entry][ray] so that equal depths coalesce.
-struct Trav {
-    int hit_obj, hit_tri; float hit_dist; int n_inner, n_leaf, n_enter, n_leave; int overflow;
-};
-
-// scene.js:508-515 with 1/d hoisted (it only changes when the ray changes space)
-__device__ __forceinline__ float slab(f3 low, f3 high, f3 o, f3 id) {
-    f3 f = (high - o) * id, n = (low - o) * id;
-    f3 tmax = max3(f, n), tmin = min3(f, n);
-    float t0 = fmax_(tmin.x, fmax_(tmin.y, tmin.z));
-    float t1 = fmin_(tmax.x, fmin_(tmax.y, tmax.z));
-    return (t1 >= t0) ? ((t1 < 0.0f) ? -1e30f : t0) : -1e30f;
-}
-// scene.js:478-506
-__device__ __forceinline__ float tri_hit(f3 o, f3 d, float4 a, float4 b, float4 c) {
-    f3 v0 = F3(a), v0v1 = F3(b) - v0, v0v2 = F3(c) - v0;
-    f3 pvec = cross3(d, v0v2);
-    float det = dot3(v0v1, pvec);
-    if (__builtin_fabsf(det) < 1e-10f) return -1.0f;
-    float i_det = 1.0f / det;
-    f3 tvec = o - v0;
-    float u = dot3(tvec, pvec) * i_det;
-    if (u < 0.0f || u > 1.0f) return -1.0f;
-    f3 qvec = cross3(tvec, v0v1);
-    float v = dot3(d, qvec) * i_det;
-    if (v < 0.0f || u + v > 1.0f) return -1.0f;
-    return dot3(v0v2, qvec) * i_det;
-}
-// scene.js:333-350 / :364-379: map o and the point o + d*hit_dist, renormalise d, recompute hit_dist
-__device__ __forceinline__ void switch_space(float4 r0, float4 r1, float4 r2, f3& o, f3& d, float& hit_dist) {
-    f3 hit_pos = o + d * hit_dist;
-    f3 new_o = xform(r0, r1, r2, o, 1.0f), new_h = xform(r0, r1, r2, hit_pos, 1.0f);
-    f3 nd = new_h - new_o;
-    hit_dist = length3(nd);
-    d = nd / hit_dist;
-    o = new_o;
-}
-
-template <bool COUNT>
-__device__ __forceinline__ Trav traverse(const SceneView& sc, f3 o, f3 d, int* lds_stack /* &[0][tid] */,
-                                         int32_t* spill /* &[0][ray] */, int64_t spill_stride) {
-    Trav R; R.n_inner = R.n_leaf = R.n_enter = R.n_leave = 0; R.overflow = 0;
-    float hit_dist = 1e6f; int hit_obj = -1, hit_tri = -1;
-    int sp = 0, node = 0, obj = -1, switch_pt = -1, iter = 0;
-    f3 id = rcp3(d);
-    while (sp >= 0) {
-        if (++iter > PT_MAX_ITERS) { R.overflow = 1; break; }
-        if (sp < switch_pt) {                                   // scene.js:330-355 leaving the object
-            const float4* ob = sc.objects + 8 * (int64_t)obj;
-            switch_space(ob[0], ob[1], ob[2], o, d, hit_dist);
-            id = rcp3(d); switch_pt = -1; obj = -1;
-            if (COUNT) R.n_leave++;
-        }
-        if (node < 0) {
-            if (obj < 0) {                                      // scene.js:357-379 entering an object
-                obj = -(node + 1);
-                const float4* ob = sc.objects + 8 * (int64_t)obj;
-                node = __float_as_int(ob[3].x); switch_pt = sp;
-                switch_space(ob[4], ob[5], ob[6], o, d, hit_dist);
-                id = rcp3(d);
-                if (COUNT) R.n_enter++;
-            } else {                                            // scene.js:380-391 triangle
-                int t = -(node + 1);
-                const float4* tr = sc.tris + 3 * (int64_t)t;
-                float dist = tri_hit(o, d, tr[0], tr[1], tr[2]);
-                if (dist > 0.0f && dist < hit_dist) { hit_dist = dist; hit_tri = t; hit_obj = obj; }
-                if (COUNT) R.n_leaf++;
-                sp -= 1;
-                node = sp < 0 ? 0 : (sp < PT_LDS_STACK ? lds_stack[sp * PT_BLOCK] : spill[(int64_t)(sp - PT_LDS_STACK) * spill_stride]);
-            }
-        } else {                                                // scene.js:392-439 inner node
-            const float4* nd = (obj < 0 ? sc.tlas : sc.blas) + 4 * (int64_t)node;
-            float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
-            if (COUNT) R.n_inner++;
-            float l_dist = slab(F3(q0), F3(q1), o, id), r_dist = slab(F3(q2), F3(q3), o, id);
-            bool l_valid = l_dist != -1e30f && l_dist < hit_dist;
-            bool r_valid = r_dist != -1e30f && r_dist < hit_dist;
-            int l_child = __float_as_int(q0.w), r_child = __float_as_int(q2.w);
-            if (l_valid && r_valid) {
-                bool l_first = l_dist < r_dist;
-                int c_idx = l_first ? l_child : r_child, f_idx = l_first ? r_child : l_child;
-                if (sp >= PT_STACK_SIZE) { R.overflow = 1; break; }
-                if (sp < PT_LDS_STACK) lds_stack[sp * PT_BLOCK] = f_idx; else spill[(int64_t)(sp - PT_LDS_STACK) * spill_stride] = f_idx;
-                sp += 1; node = c_idx;
-            } else if (l_valid) node = l_child;
-            else if (r_valid)   node = r_child;
-            else {
-                sp -= 1;
-                node = sp < 0 ? 0 : (sp < PT_LDS_STACK ? lds_stack[sp * PT_BLOCK] : spill[(int64_t)(sp - PT_LDS_STACK) * spill_stride]);
-            }
-        }
-    }
-    if (obj >= 0) {                                             // scene.js:442-466
-        const float4* ob = sc.objects + 8 * (int64_t)obj;
-        switch_space(ob[0], ob[1], ob[2], o, d, hit_dist);
-        if (COUNT) R.n_leave++;
-    }
-    R.hit_obj = hit_obj; R.hit_tri = hit_tri; R.hit_dist = hit_dist;
-    return R;
-}
-
-__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-    return v;
-}
-template <bool COUNT>
-__device__ __forceinline__ void publish_counts(const Trav& r, bool active, StepHeader* hdr) {
-    if (__any(active && r.overflow)) {
-        unsigned long long ov = wave_sum(active ? (unsigned long long)r.overflow : 0ull);
-        if (lane_id() == 0) atomicAdd(&hdr->overflow, ov);
-    }
-    if (COUNT) {
-        unsigned long long a = wave_sum(active ? r.n_inner : 0), b = wave_sum(active ? r.n_leaf : 0),
-                           c = wave_sum(active ? r.n_enter : 0), e = wave_sum(active ? r.n_leave : 0);
-        if (lane_id() == 0) { atomicAdd(&hdr->visits[0], a); atomicAdd(&hdr->visits[1], b); atomicAdd(&hdr->visits[2], c); atomicAdd(&hdr->visits[3], e); }
-    }
-}
-
-template <bool COUNT>
-__global__ __launch_bounds__(PT_BLOCK) void k_extend_queue(PathState ps, SceneView sc, StepHeader* hdr, const int32_t* __restrict__ cam_q,
-                                                           const int32_t* __restrict__ mat_q, int32_t* spill, int64_t spill_stride) {
-    __shared__ int s_stack[PT_LDS_STACK * PT_BLOCK];
-    int q = blockIdx.x * PT_BLOCK + threadIdx.x;
-    int n_cam = hdr->n_camera, n_rays = n_cam + hdr->n_material;
-    bool active = q < n_rays;
-    Trav r; r.overflow = 0; r.n_inner = r.n_leaf = r.n_enter = r.n_leave = 0;
-    if (active) {
-        int path = q < n_cam ? cam_q[q] : mat_q[q - n_cam];
-        r = traverse<COUNT>(sc, F3(ps.path_o[path]), F3(ps.path_d[path]), s_stack + threadIdx.x, spill + q, spill_stride);
-        ps.hit_obj[path] = r.hit_obj; ps.hit_tri[path] = r.hit_tri;
-    }
-    publish_counts<COUNT>(r, active, hdr);
-}
-
-__global__ __launch_bounds__(PT_BLOCK) void k_extend_direct(SceneView sc, const float4* __restrict__ o4, const float4* __restrict__ d4, int n,
-                                                            int32_t* __restrict__ hit_obj, int32_t* __restrict__ hit_tri,
-                                                            float* __restrict__ hit_dist, int4* __restrict__ counts4, int32_t* spill,
-                                                            int64_t spill_stride, StepHeader* hdr) {
-    __shared__ int s_stack[PT_LDS_STACK * PT_BLOCK];
-    int q = blockIdx.x * PT_BLOCK + threadIdx.x;
-    bool active = q < n;
-    Trav r; r.overflow = 0; r.n_inner = r.n_leaf = r.n_enter = r.n_leave = 0;
-    if (active) {
-        r = traverse<true>(sc, F3(o4[q]), F3(d4[q]), s_stack + threadIdx.x, spill + q, spill_stride);
-        hit_obj[q] = r.hit_obj; hit_tri[q] = r.hit_tri; hit_dist[q] = r.hit_dist;
-        if (counts4) counts4[q] = make_int4(r.n_inner, r.n_leaf, r.n_enter, r.n_leave);
-    }
-    publish_counts<false>(r, active, hdr);
-}
-
-// ============================================================================================
 // tonemap (display.js:98-113) + unorm8 store of the canvas
 // ============================================================================================
 __global__ __launch_bounds__(PT_BLOCK) void k_tonemap(const float4* __restrict__ image, int64_t n, uint32_t* __restrict__ rgba8) {
@@ -405,12 +250,6 @@ __global__ __launch_bounds__(PT_BLOCK) void k_tonemap(const float4* __restrict__
 }
 
 // ---- launchers -------------------------------------------------------------------------------
-size_t ptk_spill_ints(int64_t n_rays) {
-    int64_t padded = (n_rays + PT_BLOCK - 1) / PT_BLOCK * PT_BLOCK;
-    return (size_t)padded * (PT_STACK_SIZE - PT_LDS_STACK);
-}
-static int64_t spill_stride_for(int64_t n_rays) { return (n_rays + PT_BLOCK - 1) / PT_BLOCK * PT_BLOCK; }
-
 void ptk_logic(const PathState& ps, const RenderConst& rc, int first_sample, float* image, uint8_t* code, int4* blk_counts, hipStream_t s) {
     hipLaunchKernelGGL(k_logic, grid_for(rc.num_paths), dim3(PT_BLOCK), 0, s, ps, rc, first_sample, image, code, blk_counts);
 }
@@ -426,17 +265,6 @@ void ptk_generate(const PathState& ps, const RenderConst& rc, const StepHeader* 
 }
 void ptk_shade(const PathState& ps, const RenderConst& rc, const SceneView& sc, const StepHeader* hdr, const int32_t* mat_q, hipStream_t s) {
     hipLaunchKernelGGL(k_shade, grid_for(rc.num_paths), dim3(PT_BLOCK), 0, s, ps, rc, sc, hdr, mat_q);
-}
-void ptk_extend_queue(const PathState& ps, const RenderConst& rc, const SceneView& sc, StepHeader* hdr, const int32_t* cam_q,
-                      const int32_t* mat_q, int32_t* spill, int count, hipStream_t s) {
-    int64_t stride = spill_stride_for(rc.num_paths);
-    if (count) hipLaunchKernelGGL(k_extend_queue<true>, grid_for(rc.num_paths), dim3(PT_BLOCK), 0, s, ps, sc, hdr, cam_q, mat_q, spill, stride);
-    else       hipLaunchKernelGGL(k_extend_queue<false>, grid_for(rc.num_paths), dim3(PT_BLOCK), 0, s, ps, sc, hdr, cam_q, mat_q, spill, stride);
-}
-void ptk_extend_direct(const SceneView& sc, const float4* o4, const float4* d4, int n, int32_t* hit_obj, int32_t* hit_tri,
-                       float* hit_dist, int4* counts4, int32_t* spill, StepHeader* hdr, hipStream_t s) {
-    hipLaunchKernelGGL(k_extend_direct, grid_for(n), dim3(PT_BLOCK), 0, s, sc, o4, d4, n, hit_obj, hit_tri, hit_dist, counts4, spill,
-                       spill_stride_for(n), hdr);
 }
 void ptk_tonemap(const float4* image, int64_t n_pixels, uint32_t* rgba8, hipStream_t s) {
     hipLaunchKernelGGL(k_tonemap, grid_for(n_pixels), dim3(PT_BLOCK), 0, s, image, n_pixels, rgba8);
