@@ -62,10 +62,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the hot path)")
-    torch.cuda.set_device(local_rank)
+    # PT_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks then share GPUs and the
+    # reduce goes through host memory); the real thing is nccl = RCCL, one rank per GPU.
+    backend = os.environ.get("PT_BENCH_BACKEND", "nccl")
+    gpu = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
+    torch.cuda.set_device(gpu)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", gpu))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     pta = importlib.import_module("path-tracer_amd")
     factory, kwargs, w, h, spp = CONFIGS[args.config]
@@ -73,7 +80,7 @@ def main():
     desc = getattr(pta.scenes, factory)(**kwargs)
 
     stream = torch.cuda.current_stream().cuda_stream
-    dev = pta.request_device(local_rank, stream=stream)
+    dev = pta.request_device(gpu, stream=stream)
     t0 = time.time()
     scene = pta.scenes.populate(pta.init_scene(dev), desc)
     scene.build()
@@ -141,7 +148,7 @@ def main():
             "rays_per_render_per_gpu": rays // args.steps, "wavefront_iterations_per_render": int(steps_per_render),
             "scene_build_s": round(build_s, 3),
             "roofline": {"bound": "hbm", "kernel": "k_extend_queue", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(args.config),
                          "algorithmic_bytes_per_launch": round(trav_bytes / max(launches // args.steps, 1), 1),
                          "avg_launch_us": round(extend_ms * 1e3 / max(launches, 1), 3), "launches": launches,
                          "extend_share_of_step": round(ext_s / elapsed, 4)},
@@ -153,6 +160,16 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     dev.destroy()
+
+
+def pmc_traffic(config):
+    """HBM-side read bytes per extend launch from the committed rocprofv3 PMC pass of this same command
+    (profiles/traffic_<config>.json, written by tools/pmc_traffic.py from TCC_EA0_RDREQ{,_32B,_128B}); None if absent.
+    PMC counters cannot be collected from inside the timed run, so this is the profiled run's figure."""
+    f = os.path.join(ROOT, "profiles", f"traffic_{config}.json")
+    if not os.path.exists(f):
+        return None
+    return json.load(open(f)).get("hbm_read_bytes_per_launch")
 
 
 def cpu_baseline(pta, desc, w, h, spp, paths):

@@ -131,11 +131,9 @@ int read_back(pt_ctx* c, void* dst, const void* src, size_t bytes) {
 
 void enqueue_step(pt_ctx* c, int count_visits, hipEvent_t ev0, hipEvent_t ev1) {
     SceneView sv = scene_view(c);
-    ptk_logic(c->ps, c->rc, c->step == 0 ? 1 : 0, c->d_image, c->d_code, c->d_blk_counts, c->stream);
-    ptk_scan(c->d_blk_counts, c->d_blk_offsets, c->nblocks, c->d_hdr, c->stream);
+    ptk_logic(c->ps, c->rc, c->step == 0 ? 1 : 0, c->d_image, c->d_code, c->d_blk_counts, c->d_blk_offsets, c->d_hdr, c->stream);
     ptk_compact(c->ps, c->rc, c->d_code, c->d_blk_offsets, c->d_hdr, c->d_cam_q, c->d_mat_q, c->stream);
-    ptk_generate(c->ps, c->rc, c->d_hdr, c->d_cam_q, c->stream);
-    ptk_shade(c->ps, c->rc, sv, c->d_hdr, c->d_mat_q, c->stream);
+    ptk_generate_shade(c->ps, c->rc, sv, c->d_hdr, c->d_cam_q, c->d_mat_q, c->stream);
     if (ev0) (void)hipEventRecord(ev0, c->stream);
     ptk_extend_queue(c->ps, c->rc, sv, c->d_hdr, c->d_cam_q, c->d_mat_q, c->d_spill, count_visits, c->extend_variant, c->n_cus, c->stream);
     if (ev1) (void)hipEventRecord(ev1, c->stream);
@@ -172,7 +170,7 @@ int pt_create(int device_id, pt_ctx** out) {
     c->own_stream = true;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount;
-    c->extend_variant = 2;   // queue mapping, 64-thread workgroups, 16 LDS stack entries (tools/extend_ab.py: fastest on every scene)
+    c->extend_variant = 2;   // 64-thread workgroups, 16 LDS stack entries, wave-shaped trip (tools/extend_ab.py)
     if (const char* v = getenv("PT_EXTEND_VARIANT")) c->extend_variant = atoi(v);
     *out = c;
     return PT_OK;
@@ -364,7 +362,7 @@ int pt_render_init(pt_ctx* c, const pt_render_params* p) {
     if ((r = ralloc(c, &ps.pixel_index, n)) || (r = ralloc(c, &ps.num_bounces, n)) || (r = ralloc(c, &ps.random_seed, n)) ||
         (r = ralloc(c, &ps.path_throughput, n)) || (r = ralloc(c, &ps.material_throughput_pdf, n)) || (r = ralloc(c, &ps.path_o, n)) ||
         (r = ralloc(c, &ps.path_d, n)) || (r = ralloc(c, &ps.hit_obj, n)) || (r = ralloc(c, &ps.hit_tri, n)) || (r = ralloc(c, &ps.flags, n)) ||
-        (r = ralloc(c, &ps.samples_in_pixel, n)))
+        (r = ralloc(c, &ps.samples_in_pixel, n)) || (r = ralloc(c, &ps.ticket_acc, n)))
         return r;
     c->nblocks = (int)((np + PT_BLOCK - 1) / PT_BLOCK);
     if ((r = ralloc(c, &c->d_code, n)) || (r = ralloc(c, &c->d_blk_counts, (size_t)c->nblocks)) || (r = ralloc(c, &c->d_blk_offsets, (size_t)c->nblocks)) ||
@@ -426,6 +424,10 @@ int pt_render_run(pt_ctx* c, int64_t max_steps, int flags, pt_run_stats* out) {
             for (int j = 0; j < k; j++) { float ms = 0; HIPOK(c, hipEventElapsedTime(&ms, c->events[2 * j], c->events[2 * j + 1])); extend_ms += ms; launches++; }
         if (c->h_hdr->first_empty_step >= 0 || issued >= max_steps) break;
     }
+    if (c->h_hdr->first_empty_step < 0) {   // stopped by max_steps: bring the image up to date for the caller
+        ptk_flush_tickets(c->ps, c->rc.num_paths, c->d_image, c->stream);
+        HIPOK(c, hipStreamSynchronize(c->stream));
+    }
     if (out) {
         const StepHeader& h = *c->h_hdr;
         out->steps = h.first_empty_step >= 0 ? h.first_empty_step + 1 : h.step_index;
@@ -441,6 +443,7 @@ int pt_image_read(pt_ctx* c, float* rgba, int64_t n_floats) {
     if (!c->render_ready) return fail(c, PT_ERR_STATE, "pt_image_read: pt_render_init has not been called");
     if (n_floats != (int64_t)c->rc.width * c->rc.height * 4) return fail(c, PT_ERR_ARG, "pt_image_read: size mismatch");
     HIPOK(c, hipSetDevice(c->device));
+    ptk_flush_tickets(c->ps, c->rc.num_paths, c->d_image, c->stream);
     return read_back(c, rgba, c->d_image, (size_t)n_floats * 4);
 }
 
@@ -520,6 +523,7 @@ int pt_tonemap_rgba8(pt_ctx* c, const void* image_dev, int32_t width, int32_t he
     if (!image_dev) {
         if (!c->render_ready) return fail(c, PT_ERR_STATE, "pt_tonemap_rgba8: no image");
         image_dev = c->d_image; width = c->rc.width; height = c->rc.height;
+        ptk_flush_tickets(c->ps, c->rc.num_paths, c->d_image, c->stream);
     }
     if (width < 1 || height < 1) return fail(c, PT_ERR_ARG, "pt_tonemap_rgba8: bad size");
     int64_t n = (int64_t)width * height; uint32_t* d_out = nullptr; int r;

@@ -34,6 +34,7 @@ struct PathState {
     int32_t*  hit_tri;
     uint32_t* flags;
     int32_t*  samples_in_pixel;
+    float4*   ticket_acc;        // not in the reference: radiance sum + sample count of the slot's current pixel ticket
 };
 
 // Device-resident step header: queue sizes (QueuesStage*.stage_N_queue_size, path-tracer.js:173-204),
@@ -46,6 +47,7 @@ struct StepHeader {
     int64_t  total_samples;
     unsigned long long overflow; // rays stopped by the stack / iteration guards
     unsigned long long visits[4];// n_inner, n_leaf, n_enter, n_leave (counting variant only)
+    int32_t  blocks_done, pad;   // arrival counter of the logic workgroups (the last one runs the scan)
     int32_t  step_index, work_counter;   // work_counter: next ray-queue entry for the persistent extend kernel
 };
 
@@ -70,13 +72,11 @@ hipError_t pt_sort_pairs_u32(void* tmp, size_t* tmp_bytes, const uint32_t* kin, 
 
 // ---- launchers (pt_kernels_render.hip) --------------------------------------------------------
 void ptk_logic(const PathState& ps, const RenderConst& rc, int first_sample, float* image, uint8_t* code,
-               int4* blk_counts, hipStream_t s);
-void ptk_scan(const int4* blk_counts, int4* blk_offsets, int nblocks, StepHeader* hdr, hipStream_t s);
+               int4* blk_counts, int4* blk_offsets, StepHeader* hdr, hipStream_t s);
 void ptk_compact(const PathState& ps, const RenderConst& rc, const uint8_t* code, const int4* blk_offsets,
                  const StepHeader* hdr, int32_t* cam_q, int32_t* mat_q, hipStream_t s);
-void ptk_generate(const PathState& ps, const RenderConst& rc, const StepHeader* hdr, const int32_t* cam_q, hipStream_t s);
-void ptk_shade(const PathState& ps, const RenderConst& rc, const SceneView& sc, const StepHeader* hdr,
-               const int32_t* mat_q, hipStream_t s);
+void ptk_generate_shade(const PathState& ps, const RenderConst& rc, const SceneView& sc, const StepHeader* hdr,
+                        const int32_t* cam_q, const int32_t* mat_q, hipStream_t s);
 // Extend over the step's ray queue (camera ++ material).  count != 0 selects the visit-counting variant.
 void ptk_extend_queue(const PathState& ps, const RenderConst& rc, const SceneView& sc, StepHeader* hdr,
                       const int32_t* cam_q, const int32_t* mat_q, int32_t* spill, int count, int variant, int n_cus, hipStream_t s);
@@ -85,5 +85,6 @@ const char* ptk_extend_variant_name(int v);
 // Extend over n caller rays (o4/d4: float4 per ray).  counts4 (int4 per ray) may be null.
 void ptk_extend_direct(const SceneView& sc, const float4* o4, const float4* d4, int n, int32_t* hit_obj,
                        int32_t* hit_tri, float* hit_dist, int4* counts4, int32_t* spill, StepHeader* hdr, hipStream_t s);
+void ptk_flush_tickets(const PathState& ps, int num_paths, float* image, hipStream_t s);
 void ptk_tonemap(const float4* image, int64_t n_pixels, uint32_t* rgba8, hipStream_t s);
 size_t ptk_spill_ints(int64_t n_rays);   // ints needed in the spill buffer for a launch over n_rays

@@ -133,6 +133,62 @@ __device__ __forceinline__ void trav_finish(const SceneView& sc, Ray& r) {
     }
 }
 
+// The same trip written for the wave: one pop site shared by the triangle and the "both children missed"
+// cases, selects instead of nested branches for the child choice, and a wave-uniform test that keeps the whole
+// wave on LDS-only stack code while no lane is deeper than the LDS share.  Entering an object returns to the
+// caller like the reference's loop does; per-ray operation order, and therefore every result, is unchanged.
+template <bool COUNT, class STK, int LDS_N, int BLOCK>
+__device__ __forceinline__ bool trav_step2(const SceneView& sc, Ray& r, const STK& stk, int* lds) {
+    if (++r.iter > PT_MAX_ITERS) { r.overflow = 1; return false; }
+    if (r.sp < r.switch_pt) {                                   // scene.js:330-355
+        const float4* ob = sc.objects + 8 * (int64_t)r.obj;
+        switch_space(ob[0], ob[1], ob[2], r);
+        r.switch_pt = -1; r.obj = -1;
+        if (COUNT) r.n_leave++;
+    }
+    bool pop, push = false; int nxt = 0, far = 0;
+    if (r.node < 0) {
+        if (r.obj < 0) {                                        // scene.js:357-379
+            r.obj = -(r.node + 1);
+            const float4* ob = sc.objects + 8 * (int64_t)r.obj;
+            r.node = __float_as_int(ob[3].x); r.switch_pt = r.sp;
+            switch_space(ob[4], ob[5], ob[6], r);
+            if (COUNT) r.n_enter++;
+            return true;
+        }
+        int t = -(r.node + 1);                                  // scene.js:380-391
+        const float4* tr = sc.tris + 3 * (int64_t)t;
+        float dist = tri_hit(r.o, r.d, tr[0], tr[1], tr[2]);
+        if (dist > 0.0f && dist < r.hit_dist) { r.hit_dist = dist; r.hit_tri = t; r.hit_obj = r.obj; }
+        if (COUNT) r.n_leaf++;
+        pop = true;
+    } else {                                                    // scene.js:392-439
+        const float4* nd = (r.obj < 0 ? sc.tlas : sc.blas) + 4 * (int64_t)r.node;
+        float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+        if (COUNT) r.n_inner++;
+        float l_dist = slab(F3(q0), F3(q1), r.o, r.id), r_dist = slab(F3(q2), F3(q3), r.o, r.id);
+        bool l_valid = l_dist != -1e30f && l_dist < r.hit_dist;
+        bool r_valid = r_dist != -1e30f && r_dist < r.hit_dist;
+        int l_child = __float_as_int(q0.w), r_child = __float_as_int(q2.w);
+        bool l_first = l_dist < r_dist;
+        push = l_valid && r_valid;
+        pop = !(l_valid || r_valid);
+        bool take_l = push ? l_first : l_valid;
+        nxt = take_l ? l_child : r_child;
+        far = l_first ? r_child : l_child;
+    }
+    if (push && r.sp >= PT_STACK_SIZE) { r.overflow = 1; return false; }
+    if (__all(r.sp < LDS_N)) {                                  // wave-uniform: nobody touches the spill this trip
+        if (push) { lds[r.sp * BLOCK] = far; r.sp += 1; }
+        if (pop) { r.sp -= 1; if (r.sp < 0) return false; nxt = lds[r.sp * BLOCK]; }
+    } else {
+        if (push) { stk.put(r.sp, far); r.sp += 1; }
+        if (pop) { r.sp -= 1; if (r.sp < 0) return false; nxt = stk.get(r.sp); }
+    }
+    r.node = nxt;
+    return true;
+}
+
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
     return v;
@@ -149,9 +205,10 @@ __device__ __forceinline__ void publish(unsigned long long ov, unsigned long lon
 }
 
 // --------------------------------------------------------------------------------------------
-// Variant A: one launch thread per queue entry (the reference's mapping, ray-trace.js:55-60)
+// The extend kernel: one launch thread per ray-queue entry (the reference's mapping, ray-trace.js:55-60).
+// STEP selects the trip implementation (1 = literal state machine, 2 = wave-shaped trip).
 // --------------------------------------------------------------------------------------------
-template <int LDS_N, int BLOCK, bool COUNT>
+template <int LDS_N, int BLOCK, bool COUNT, int STEP>
 __global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView sc, StepHeader* hdr, const int32_t* __restrict__ cam_q,
                                                         const int32_t* __restrict__ mat_q, int32_t* spill, int64_t spill_stride) {
     __shared__ int s_stack[LDS_N * BLOCK];
@@ -162,61 +219,12 @@ __global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView 
         int path = q < n_cam ? cam_q[q] : mat_q[q - n_cam];
         ray_init(r, F3(ps.path_o[path]), F3(ps.path_d[path]));
         Stack<LDS_N, BLOCK> stk{s_stack + threadIdx.x, spill + q, spill_stride};
-        while (trav_step<COUNT>(sc, r, stk)) {}
+        if (STEP == 1) { while (trav_step<COUNT>(sc, r, stk)) {} }
+        else           { while (trav_step2<COUNT, Stack<LDS_N, BLOCK>, LDS_N, BLOCK>(sc, r, stk, s_stack + threadIdx.x)) {} }
         trav_finish<COUNT>(sc, r);
         ps.hit_obj[path] = r.hit_obj; ps.hit_tri[path] = r.hit_tri;
     }
     publish<COUNT>(r.overflow, r.n_inner, r.n_leaf, r.n_enter, r.n_leave, hdr);
-}
-
-// --------------------------------------------------------------------------------------------
-// Variant B: persistent waves with lane refill.  The grid is sized to the machine, not to the queue.
-// The queue is cut into one contiguous share per wave (no atomics: one device-wide counter saturates at
-// ~88 dequeues/us, far below the rate short rays need); inside its share a wave hands the next ray to any
-// lane whose ray has finished, so short rays do not leave lanes idle while the longest ray of the wave is
-// still walking.  Exit: a wave leaves once its share is used up and all its lanes are idle.
-// --------------------------------------------------------------------------------------------
-template <int LDS_N, int BLOCK, bool COUNT>
-__global__ __launch_bounds__(BLOCK) void k_extend_persist(PathState ps, SceneView sc, StepHeader* hdr, const int32_t* __restrict__ cam_q,
-                                                          const int32_t* __restrict__ mat_q, int32_t* spill, int64_t spill_stride,
-                                                          int refill_below) {
-    __shared__ int s_stack[LDS_N * BLOCK];
-    const int n_cam = hdr->n_camera, n_rays = n_cam + hdr->n_material;
-    const int slot = blockIdx.x * BLOCK + threadIdx.x;
-    const int n_waves = gridDim.x * (BLOCK / 64), wave = slot >> 6;
-    const int share = ((n_rays + n_waves - 1) / n_waves + 63) & ~63;      // whole batches of 64
-    int next = min(wave * share, n_rays); const int end = min(next + share, n_rays);
-    Stack<LDS_N, BLOCK> stk{s_stack + threadIdx.x, spill + slot, spill_stride};
-    Ray r; ray_init(r, F3(0, 0, 1), F3(0, 0, 1));
-    bool busy = false; int path = 0;
-    unsigned long long ov = 0, ca = 0, cb = 0, cc = 0, ce = 0;
-    for (;;) {
-        unsigned long long idle = __ballot(!busy);
-        int n_idle = __popcll(idle);
-        if (next < end && n_idle > 64 - refill_below) {          // fewer than refill_below lanes busy: hand out rays
-            if (!busy) {
-                int q = next + rank_below(idle);
-                if (q < end) {
-                    path = q < n_cam ? cam_q[q] : mat_q[q - n_cam];
-                    ray_init(r, F3(ps.path_o[path]), F3(ps.path_d[path]));
-                    busy = true;
-                }
-            }
-            next += n_idle;                                      // wave-uniform
-            idle = __ballot(!busy); n_idle = __popcll(idle);
-        }
-        if (n_idle == 64) break;                                 // share used up and every lane idle
-#pragma unroll 1
-        for (int k = 0; k < 4; k++) {                            // a few trips between refill checks
-            if (busy && !trav_step<COUNT>(sc, r, stk)) {
-                trav_finish<COUNT>(sc, r);
-                ps.hit_obj[path] = r.hit_obj; ps.hit_tri[path] = r.hit_tri;
-                ov += r.overflow; ca += r.n_inner; cb += r.n_leaf; cc += r.n_enter; ce += r.n_leave;
-                busy = false;
-            }
-        }
-    }
-    publish<COUNT>(ov, ca, cb, cc, ce, hdr);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -245,43 +253,27 @@ static int64_t pad_to(int64_t n, int64_t m) { return (n + m - 1) / m * m; }
 // The spill is sized for the smallest LDS share any variant uses (16 entries) and the largest slot count.
 size_t ptk_spill_ints(int64_t n_rays) { return (size_t)pad_to(n_rays, 256) * (PT_STACK_SIZE - 16); }
 
-template <int LDS_N, int BLOCK>
+template <int LDS_N, int BLOCK, int STEP>
 static void launch_queue(const PathState& ps, int num_paths, const SceneView& sc, StepHeader* hdr, const int32_t* cam_q,
                          const int32_t* mat_q, int32_t* spill, int count, hipStream_t s) {
     int64_t stride = pad_to(num_paths, 256);
     dim3 grid((unsigned)((num_paths + BLOCK - 1) / BLOCK));
-    if (count) hipLaunchKernelGGL((k_extend_queue<LDS_N, BLOCK, true>), grid, dim3(BLOCK), 0, s, ps, sc, hdr, cam_q, mat_q, spill, stride);
-    else       hipLaunchKernelGGL((k_extend_queue<LDS_N, BLOCK, false>), grid, dim3(BLOCK), 0, s, ps, sc, hdr, cam_q, mat_q, spill, stride);
-}
-template <int LDS_N, int BLOCK>
-static void launch_persist(const PathState& ps, int num_paths, const SceneView& sc, StepHeader* hdr, const int32_t* cam_q,
-                           const int32_t* mat_q, int32_t* spill, int count, int n_cus, int refill_below, int persist_div, hipStream_t s) {
-    int64_t stride = pad_to(num_paths, 256);
-    int64_t want = (num_paths + BLOCK - 1) / BLOCK, resident = (int64_t)n_cus * (2048 / BLOCK) / (persist_div > 0 ? persist_div : 1);   // 32 waves per CU
-    dim3 grid((unsigned)(want < resident ? want : resident));
-    if (count) hipLaunchKernelGGL((k_extend_persist<LDS_N, BLOCK, true>), grid, dim3(BLOCK), 0, s, ps, sc, hdr, cam_q, mat_q, spill, stride, refill_below);
-    else       hipLaunchKernelGGL((k_extend_persist<LDS_N, BLOCK, false>), grid, dim3(BLOCK), 0, s, ps, sc, hdr, cam_q, mat_q, spill, stride, refill_below);
+    if (count) hipLaunchKernelGGL((k_extend_queue<LDS_N, BLOCK, true, STEP>), grid, dim3(BLOCK), 0, s, ps, sc, hdr, cam_q, mat_q, spill, stride);
+    else       hipLaunchKernelGGL((k_extend_queue<LDS_N, BLOCK, false, STEP>), grid, dim3(BLOCK), 0, s, ps, sc, hdr, cam_q, mat_q, spill, stride);
 }
 
-int ptk_extend_num_variants() { return 8; }
-const char* ptk_extend_variant_name(int v) {
-    static const char* names[] = {"queue b256 lds24", "queue b256 lds16", "queue b64 lds16", "persist b64 lds16 refill<64",
-                                  "persist b64 lds16 refill<48", "persist b64 lds16 refill<32", "persist b64 lds16 refill<48 half grid", "queue b64 lds24"};
-    return (v >= 0 && v < 8) ? names[v] : "?";
-}
+static const char* kVariantNames[] = {"b256 lds24 literal trip", "b64 lds16 literal trip", "b64 lds16 wave-shaped trip", "b256 lds16 wave-shaped trip"};
+int ptk_extend_num_variants() { return 4; }
+const char* ptk_extend_variant_name(int v) { return (v >= 0 && v < 4) ? kVariantNames[v] : "?"; }
 void ptk_extend_queue(const PathState& ps, const RenderConst& rc, const SceneView& sc, StepHeader* hdr, const int32_t* cam_q,
                       const int32_t* mat_q, int32_t* spill, int count, int variant, int n_cus, hipStream_t s) {
-    int np = rc.num_paths;
+    int np = rc.num_paths; (void)n_cus;
     switch (variant) {
+        case 0: launch_queue<24, 256, 1>(ps, np, sc, hdr, cam_q, mat_q, spill, count, s); break;
+        case 1: launch_queue<16, 64, 1>(ps, np, sc, hdr, cam_q, mat_q, spill, count, s); break;
         default:
-        case 0: launch_queue<24, 256>(ps, np, sc, hdr, cam_q, mat_q, spill, count, s); break;
-        case 1: launch_queue<16, 256>(ps, np, sc, hdr, cam_q, mat_q, spill, count, s); break;
-        case 2: launch_queue<16, 64>(ps, np, sc, hdr, cam_q, mat_q, spill, count, s); break;
-        case 3: launch_persist<16, 64>(ps, np, sc, hdr, cam_q, mat_q, spill, count, n_cus, 64, 1, s); break;
-        case 4: launch_persist<16, 64>(ps, np, sc, hdr, cam_q, mat_q, spill, count, n_cus, 48, 1, s); break;
-        case 5: launch_persist<16, 64>(ps, np, sc, hdr, cam_q, mat_q, spill, count, n_cus, 32, 1, s); break;
-        case 6: launch_persist<16, 64>(ps, np, sc, hdr, cam_q, mat_q, spill, count, n_cus, 48, 2, s); break;
-        case 7: launch_queue<24, 64>(ps, np, sc, hdr, cam_q, mat_q, spill, count, s); break;
+        case 2: launch_queue<16, 64, 2>(ps, np, sc, hdr, cam_q, mat_q, spill, count, s); break;
+        case 3: launch_queue<16, 256, 2>(ps, np, sc, hdr, cam_q, mat_q, spill, count, s); break;
     }
 }
 void ptk_extend_direct(const SceneView& sc, const float4* o4, const float4* d4, int n, int32_t* hit_obj, int32_t* hit_tri,

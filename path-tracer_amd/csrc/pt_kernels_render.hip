@@ -1,13 +1,13 @@
-// pt_kernels_render.hip -- the wavefront integrator on gfx950.
+// pt_kernels_render.hip -- the wavefront integrator on gfx950 (extend is in pt_kernels_extend.hip).
 //
-// One step() = logic -> scan -> compact -> generate -> shade -> extend, all on one stream, no host
-// round trip in between (the reference awaits the queue after each of its four dispatches,
-// path-tracer.js:86-107).  Queue appends are order-preserving: wave64 ballots give each lane its
-// rank, one scan over per-workgroup counts gives each workgroup its base, so every queue is in
-// ascending path-slot order and pixel tickets are handed out in slot order (the reference's
-// canonical serial order; its own order is a race, logic.js:158,168,205,213).
-// Because every camera-queue and every material-queue entry produces exactly one ray, the ray-trace
-// queue (QueuesStage3.ray_trace_queue) is the concatenation camera ++ material and is never stored.
+// One step() = logic -> scan -> compact -> generate+shade -> extend, all on one stream, no host round trip
+// in between (the reference awaits the queue after each of its four dispatches, path-tracer.js:86-107).
+// Queue appends are order-preserving: wave64 ballots give each lane its rank, one scan over per-workgroup
+// counts gives each workgroup its base, so every queue is in ascending path-slot order and pixel tickets are
+// handed out in slot order (the reference's canonical serial order; its own order is a race,
+// logic.js:158,168,205,213).  Because every camera-queue and every material-queue entry produces exactly one
+// ray, the ray-trace queue (QueuesStage3.ray_trace_queue) is the concatenation camera ++ material and is
+// never stored.
 #include "pt_internal.h"
 #include "pt_math.cuh"
 
@@ -20,12 +20,48 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int rank_below(unsigned long long mask) {   // set bits below my lane
     return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
 }
+__device__ __forceinline__ int4 add4(int4 a, int4 b) { return make_int4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// ============================================================================================
+// scan: exclusive prefix over the per-workgroup counts by ONE workgroup (the reference's global atomics,
+// logic.js:163-170,199-219); publishes queue sizes, ticket base and run totals in the StepHeader.
+// ============================================================================================
+__device__ void scan_blocks(const int4* blk_counts, int4* blk_offsets, int nblocks, StepHeader* hdr, int4* s_wave /* [PT_BLOCK/64] */) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (nblocks + PT_BLOCK - 1) / PT_BLOCK, b0 = min(tid * per, nblocks), b1 = min(b0 + per, nblocks);
+    int4 sum = make_int4(0, 0, 0, 0);
+    for (int b = b0; b < b1; b++) sum = add4(sum, blk_counts[b]);
+    int4 inc = sum;
+    for (int off = 1; off < 64; off <<= 1) {   // inclusive scan inside the wave
+        int x = __shfl_up(inc.x, off), y = __shfl_up(inc.y, off), z = __shfl_up(inc.z, off), w = __shfl_up(inc.w, off);
+        if (lane >= off) inc = add4(inc, make_int4(x, y, z, w));
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    int4 run = make_int4(inc.x - sum.x, inc.y - sum.y, inc.z - sum.z, 0), tot = make_int4(0, 0, 0, 0);
+    for (int w = 0; w < PT_BLOCK / 64; w++) { if (w < wave) run = add4(run, s_wave[w]); tot = add4(tot, s_wave[w]); }
+    for (int b = b0; b < b1; b++) { blk_offsets[b] = make_int4(run.x, run.y, run.z, 0); run = add4(run, blk_counts[b]); }
+    if (tid == 0) {
+        hdr->n_camera = tot.x; hdr->n_material = tot.y; hdr->n_rays = tot.x + tot.y;
+        hdr->ticket_base = hdr->pixel_counter;
+        hdr->pixel_counter += tot.z;
+        hdr->total_rays += (int64_t)tot.x + tot.y;
+        hdr->total_samples += tot.w;
+        if (tot.x + tot.y == 0 && hdr->first_empty_step < 0) hdr->first_empty_step = hdr->step_index;
+        hdr->step_index += 1;
+        hdr->work_counter = 0;
+    }
+}
 
 // ============================================================================================
 // logic (logic.js:62-152): per-slot state machine, image accumulation, decisions
 // ============================================================================================
 // code bits: 1 = camera queue, 2 = material queue, 4 = wants a pixel ticket.
 // blk_counts[b] = {#camera, #material, #tickets, #finished samples} of workgroup b.
+// Image accumulation: a slot owns its pixel for the 8 samples of a ticket (logic.js:6,129), so the samples are
+// summed in the slot's ticket accumulator and reach the image with ONE group of float atomics per ticket instead
+// of one per sample (scattered float atomics are the slowest memory operation on this chip).  The reference's
+// own add order is a race (logic.js:222-233); sample counts stay exact.
 __global__ __launch_bounds__(PT_BLOCK) void k_logic(PathState ps, RenderConst rc, int first_sample, float* __restrict__ image,
                                                     uint8_t* __restrict__ code_out, int4* __restrict__ blk_counts) {
     __shared__ int4 s_wave[PT_BLOCK / 64];
@@ -63,10 +99,16 @@ __global__ __launch_bounds__(PT_BLOCK) void k_logic(PathState ps, RenderConst rc
             ps.path_throughput[i] = make_float4(tp.x, tp.y, tp.z, 0.0f);
             ps.num_bounces[i] = nb;
             ps.flags[i] = 0u;
-            if (finished || contrib.x != 0.0f || contrib.y != 0.0f || contrib.z != 0.0f) {   // logic.js:145-150
-                float* px = image + 4 * (int64_t)ps.pixel_index[i];
-                unsafeAtomicAdd(px + 0, contrib.x); unsafeAtomicAdd(px + 1, contrib.y);
-                unsafeAtomicAdd(px + 2, contrib.z); unsafeAtomicAdd(px + 3, finished ? 1.0f : 0.0f);
+            if (finished) {                                                      // logic.js:145-150
+                float4 acc = ps.ticket_acc[i];
+                acc.x += contrib.x; acc.y += contrib.y; acc.z += contrib.z; acc.w += 1.0f;
+                if (code & 4u) {                                                 // ticket complete: flush to the image
+                    float* px = image + 4 * (int64_t)ps.pixel_index[i];
+                    unsafeAtomicAdd(px + 0, acc.x); unsafeAtomicAdd(px + 1, acc.y);
+                    unsafeAtomicAdd(px + 2, acc.z); unsafeAtomicAdd(px + 3, acc.w);
+                    acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+                ps.ticket_acc[i] = acc;
             }
         }
     }
@@ -77,52 +119,17 @@ __global__ __launch_bounds__(PT_BLOCK) void k_logic(PathState ps, RenderConst rc
     __syncthreads();
     if (threadIdx.x == 0) {
         int4 t = s_wave[0];
-        for (int w = 1; w < PT_BLOCK / 64; w++) { t.x += s_wave[w].x; t.y += s_wave[w].y; t.z += s_wave[w].z; t.w += s_wave[w].w; }
+        for (int w = 1; w < PT_BLOCK / 64; w++) t = add4(t, s_wave[w]);
         blk_counts[blockIdx.x] = t;
     }
 }
 
-// ============================================================================================
-// scan: exclusive prefix over the per-workgroup counts; publishes queue sizes and ticket base
-// ============================================================================================
-__global__ __launch_bounds__(1024) void k_scan(const int4* __restrict__ blk_counts, int4* __restrict__ blk_offsets, int nblocks,
-                                               StepHeader* hdr) {
-    __shared__ int4 s_wave[16];
-    __shared__ int4 s_carry;
-    int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_carry = make_int4(0, 0, 0, 0);
-    __syncthreads();
-    for (int base = 0; base < nblocks; base += 1024) {
-        int  b = base + tid;
-        int4 v = b < nblocks ? blk_counts[b] : make_int4(0, 0, 0, 0);
-        int4 inc = v;
-        for (int off = 1; off < 64; off <<= 1) {   // inclusive scan inside the wave
-            int x = __shfl_up(inc.x, off), y = __shfl_up(inc.y, off), z = __shfl_up(inc.z, off), w = __shfl_up(inc.w, off);
-            if (lane >= off) { inc.x += x; inc.y += y; inc.z += z; inc.w += w; }
-        }
-        if (lane == 63) s_wave[wave] = inc;
-        __syncthreads();
-        int4 wbase = make_int4(0, 0, 0, 0);
-        for (int w = 0; w < wave; w++) { wbase.x += s_wave[w].x; wbase.y += s_wave[w].y; wbase.z += s_wave[w].z; wbase.w += s_wave[w].w; }
-        int4 carry = s_carry;
-        if (b < nblocks)
-            blk_offsets[b] = make_int4(carry.x + wbase.x + inc.x - v.x, carry.y + wbase.y + inc.y - v.y,
-                                       carry.z + wbase.z + inc.z - v.z, 0);
-        __syncthreads();
-        if (tid == 1023) s_carry = make_int4(carry.x + wbase.x + inc.x, carry.y + wbase.y + inc.y, carry.z + wbase.z + inc.z, carry.w + wbase.w + inc.w);
-        __syncthreads();
-    }
-    if (tid == 0) {
-        int4 tot = s_carry;
-        hdr->n_camera = tot.x; hdr->n_material = tot.y; hdr->n_rays = tot.x + tot.y;
-        hdr->ticket_base = hdr->pixel_counter;
-        hdr->pixel_counter += tot.z;
-        hdr->total_rays += (int64_t)tot.x + tot.y;
-        hdr->total_samples += tot.w;
-        if (tot.x + tot.y == 0 && hdr->first_empty_step < 0) hdr->first_empty_step = hdr->step_index;
-        hdr->step_index += 1;
-        hdr->work_counter = 0;
-    }
+// The scan is its own one-workgroup launch.  (Folding it into k_logic as "the last workgroup to arrive scans" was
+// measured: 3907 arrivals on one device-scope counter plus a release fence per workgroup took k_logic from 57 to
+// 155 us -- a kernel boundary costs ~2 us.)
+__global__ __launch_bounds__(PT_BLOCK) void k_scan(const int4* __restrict__ blk_counts, int4* __restrict__ blk_offsets, int nblocks, StepHeader* hdr) {
+    __shared__ int4 s_wave[PT_BLOCK / 64];
+    scan_blocks(blk_counts, blk_offsets, nblocks, hdr, s_wave);
 }
 
 // ============================================================================================
@@ -155,11 +162,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_compact(PathState ps, RenderConst 
 // ============================================================================================
 // generate (camera.js:60-118)
 // ============================================================================================
-__global__ __launch_bounds__(PT_BLOCK) void k_generate(PathState ps, RenderConst rc, const StepHeader* __restrict__ hdr,
-                                                       const int32_t* __restrict__ cam_q) {
-    int q = blockIdx.x * PT_BLOCK + threadIdx.x;
-    if (q >= hdr->n_camera) return;
-    int path = cam_q[q];
+__device__ __forceinline__ void generate_one(const PathState& ps, const RenderConst& rc, int path) {
     int px = ps.pixel_index[path];
     float seed = ps.random_seed[path];
     float2 r2 = rand2(seed);
@@ -183,11 +186,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_generate(PathState ps, RenderConst
 // ============================================================================================
 // shade (material.js:75-120; scene.js:204-258 get_triangle_hit_info)
 // ============================================================================================
-__global__ __launch_bounds__(PT_BLOCK) void k_shade(PathState ps, RenderConst rc, SceneView sc, const StepHeader* __restrict__ hdr,
-                                                    const int32_t* __restrict__ mat_q) {
-    int q = blockIdx.x * PT_BLOCK + threadIdx.x;
-    if (q >= hdr->n_material) return;
-    int path = mat_q[q];
+__device__ __forceinline__ void shade_one(const PathState& ps, const SceneView& sc, int path) {
     f3 o = F3(ps.path_o[path]), d = F3(ps.path_d[path]);
     int hit_obj = ps.hit_obj[path], hit_tri = ps.hit_tri[path];
     const float4* ob = sc.objects + 8 * (int64_t)hit_obj;
@@ -230,6 +229,32 @@ __global__ __launch_bounds__(PT_BLOCK) void k_shade(PathState ps, RenderConst rc
     ps.path_d[path] = make_float4(nd.x, nd.y, nd.z, 0.0f);
 }
 
+// generate and shade share one launch: workgroups [0, ceil(n_camera/256)) generate, the following ones shade
+// (every workgroup is all-camera or all-material, so the two bodies never diverge inside a wave).
+__global__ __launch_bounds__(PT_BLOCK) void k_generate_shade(PathState ps, RenderConst rc, SceneView sc, const StepHeader* __restrict__ hdr,
+                                                             const int32_t* __restrict__ cam_q, const int32_t* __restrict__ mat_q) {
+    const int n_cam = hdr->n_camera, cam_blocks = (n_cam + PT_BLOCK - 1) / PT_BLOCK;
+    if ((int)blockIdx.x < cam_blocks) {
+        int q = blockIdx.x * PT_BLOCK + threadIdx.x;
+        if (q < n_cam) generate_one(ps, rc, cam_q[q]);
+    } else {
+        int q = (blockIdx.x - cam_blocks) * PT_BLOCK + threadIdx.x;
+        if (q < hdr->n_material) shade_one(ps, sc, mat_q[q]);
+    }
+}
+
+// Adds the unfinished tickets' partial sums to the image (and clears them) so that a host looking at the image in
+// the middle of a render sees every finished sample, as the reference's per-sample adds would show.
+__global__ __launch_bounds__(PT_BLOCK) void k_flush_tickets(PathState ps, int num_paths, float* __restrict__ image) {
+    int i = blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (i >= num_paths) return;
+    float4 acc = ps.ticket_acc[i];
+    if (acc.w == 0.0f) return;
+    float* px = image + 4 * (int64_t)ps.pixel_index[i];
+    unsafeAtomicAdd(px + 0, acc.x); unsafeAtomicAdd(px + 1, acc.y); unsafeAtomicAdd(px + 2, acc.z); unsafeAtomicAdd(px + 3, acc.w);
+    ps.ticket_acc[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
 // ============================================================================================
 // tonemap (display.js:98-113) + unorm8 store of the canvas
 // ============================================================================================
@@ -250,21 +275,23 @@ __global__ __launch_bounds__(PT_BLOCK) void k_tonemap(const float4* __restrict__
 }
 
 // ---- launchers -------------------------------------------------------------------------------
-void ptk_logic(const PathState& ps, const RenderConst& rc, int first_sample, float* image, uint8_t* code, int4* blk_counts, hipStream_t s) {
-    hipLaunchKernelGGL(k_logic, grid_for(rc.num_paths), dim3(PT_BLOCK), 0, s, ps, rc, first_sample, image, code, blk_counts);
-}
-void ptk_scan(const int4* blk_counts, int4* blk_offsets, int nblocks, StepHeader* hdr, hipStream_t s) {
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, blk_counts, blk_offsets, nblocks, hdr);
+void ptk_logic(const PathState& ps, const RenderConst& rc, int first_sample, float* image, uint8_t* code, int4* blk_counts,
+               int4* blk_offsets, StepHeader* hdr, hipStream_t s) {
+    int nblocks = (rc.num_paths + PT_BLOCK - 1) / PT_BLOCK;
+    hipLaunchKernelGGL(k_logic, dim3(nblocks), dim3(PT_BLOCK), 0, s, ps, rc, first_sample, image, code, blk_counts);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(PT_BLOCK), 0, s, blk_counts, blk_offsets, nblocks, hdr);
 }
 void ptk_compact(const PathState& ps, const RenderConst& rc, const uint8_t* code, const int4* blk_offsets, const StepHeader* hdr,
                  int32_t* cam_q, int32_t* mat_q, hipStream_t s) {
     hipLaunchKernelGGL(k_compact, grid_for(rc.num_paths), dim3(PT_BLOCK), 0, s, ps, rc, code, blk_offsets, hdr, cam_q, mat_q);
 }
-void ptk_generate(const PathState& ps, const RenderConst& rc, const StepHeader* hdr, const int32_t* cam_q, hipStream_t s) {
-    hipLaunchKernelGGL(k_generate, grid_for(rc.num_paths), dim3(PT_BLOCK), 0, s, ps, rc, hdr, cam_q);
+void ptk_generate_shade(const PathState& ps, const RenderConst& rc, const SceneView& sc, const StepHeader* hdr, const int32_t* cam_q,
+                        const int32_t* mat_q, hipStream_t s) {
+    dim3 grid((unsigned)((rc.num_paths + PT_BLOCK - 1) / PT_BLOCK + 1));   // ceil(c/256) + ceil(m/256) <= this whenever c + m <= num_paths
+    hipLaunchKernelGGL(k_generate_shade, grid, dim3(PT_BLOCK), 0, s, ps, rc, sc, hdr, cam_q, mat_q);
 }
-void ptk_shade(const PathState& ps, const RenderConst& rc, const SceneView& sc, const StepHeader* hdr, const int32_t* mat_q, hipStream_t s) {
-    hipLaunchKernelGGL(k_shade, grid_for(rc.num_paths), dim3(PT_BLOCK), 0, s, ps, rc, sc, hdr, mat_q);
+void ptk_flush_tickets(const PathState& ps, int num_paths, float* image, hipStream_t s) {
+    hipLaunchKernelGGL(k_flush_tickets, grid_for(num_paths), dim3(PT_BLOCK), 0, s, ps, num_paths, image);
 }
 void ptk_tonemap(const float4* image, int64_t n_pixels, uint32_t* rgba8, hipStream_t s) {
     hipLaunchKernelGGL(k_tonemap, grid_for(n_pixels), dim3(PT_BLOCK), 0, s, image, n_pixels, rgba8);

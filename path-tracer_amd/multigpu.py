@@ -30,5 +30,10 @@ def reduce_image(image_tensor, dst=0):
     """Sum the per-rank accumulation buffers onto rank dst (backend nccl = RCCL on ROCm; gloo in CPU tests)."""
     import torch.distributed as dist
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.reduce(image_tensor, dst=dst, op=dist.ReduceOp.SUM)
+        if dist.get_backend() == "gloo" and image_tensor.is_cuda:      # rehearsal on a box with fewer GPUs than ranks
+            host = image_tensor.cpu()
+            dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM)
+            image_tensor.copy_(host)
+        else:
+            dist.reduce(image_tensor, dst=dst, op=dist.ReduceOp.SUM)
     return image_tensor
