@@ -382,7 +382,7 @@ static inline float tri_intersect(v3 o, v3 d, const orc_tri* tr) {
     return v3_dot(v0v2, qvec) * i_det;
 }
 
-typedef struct { int32_t hit_obj, hit_tri; float hit_dis; int32_t n_inner, n_leaf, n_enter, n_leave; int overflow; } hit_res;
+typedef struct { int32_t hit_obj, hit_tri; float hit_dis; int32_t n_inner, n_leaf, n_enter, n_leave; int overflow; int max_sp; } hit_res;
 
 /* scene.js:330-355 / :357-379: map o and the point o+d*hit_dist, renormalise d, recompute hit_dist */
 static inline void switch_space(const float m[3][4], v3* o, v3* d, float* hit_dist) {
@@ -437,6 +437,7 @@ static hit_res intersect_bvh(const orc_scene* s, v3 o, v3 d) {
                 else                 { c_idx = nd->r_child; f_idx = nd->l_child; }
                 if (stack_ptr >= ORC_STACK_SIZE) { R.overflow = 1; break; }
                 stack[stack_ptr] = f_idx; stack_ptr += 1; node_idx = c_idx;
+                if (stack_ptr > R.max_sp) R.max_sp = stack_ptr;
             } else if (l_valid) node_idx = nd->l_child;
             else if (r_valid)   node_idx = nd->r_child;
             else { stack_ptr -= 1; node_idx = stack_ptr >= 0 ? stack[stack_ptr] : 0; }
@@ -450,21 +451,25 @@ static hit_res intersect_bvh(const orc_scene* s, v3 o, v3 d) {
     return R;
 }
 
+static int g_last_max_depth = 0;   /* deepest stack of the last orc_trace_rays call (tests: is the spill exercised?) */
 int64_t orc_trace_rays(const orc_scene* s, const float* o3, const float* d3, int64_t n, int32_t* hit_obj,
                        int32_t* hit_tri, float* hit_dist, int32_t* counts4, int threads) {
-    int64_t overflow = 0;
+    int64_t overflow = 0; int max_sp = 0;
     if (threads < 1) threads = 1;
-#pragma omp parallel for schedule(dynamic, 256) num_threads(threads) reduction(+ : overflow)
+#pragma omp parallel for schedule(dynamic, 256) num_threads(threads) reduction(+ : overflow) reduction(max : max_sp)
     for (int64_t i = 0; i < n; i++) {
         hit_res r = intersect_bvh(s, v3_ld(o3 + 3 * i), v3_ld(d3 + 3 * i));
+        if (r.max_sp > max_sp) max_sp = r.max_sp;
         if (hit_obj) hit_obj[i] = r.hit_obj;
         if (hit_tri) hit_tri[i] = r.hit_tri;
         if (hit_dist) hit_dist[i] = r.hit_dis;
         if (counts4) { counts4[4 * i] = r.n_inner; counts4[4 * i + 1] = r.n_leaf; counts4[4 * i + 2] = r.n_enter; counts4[4 * i + 3] = r.n_leave; }
         overflow += r.overflow;
     }
+    g_last_max_depth = max_sp;
     return overflow;
 }
+int orc_trace_max_depth(void) { return g_last_max_depth; }
 
 /* Independent pin (no BVH, no hit_dist round trips): for every object in TLAS-sorted order map
  * the ray to object space exactly as an "enter" from a fresh ray would, test every triangle of

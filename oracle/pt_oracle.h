@@ -81,6 +81,7 @@ const int32_t*    orc_scene_mesh_perm(const orc_scene*, int mesh);   /* per-mesh
 /* counts[4] per ray (optional): n_inner, n_leaf, n_enter, n_leave ; returns #stack overflows */
 int64_t orc_trace_rays(const orc_scene*, const float* o3, const float* d3, int64_t n,
                        int32_t* hit_obj, int32_t* hit_tri, float* hit_dist, int32_t* counts4, int threads);
+int orc_trace_max_depth(void);   /* deepest traversal stack seen by the last orc_trace_rays call */
 /* independent pin: test every instance x every triangle, no BVH. ties -> first in (obj,tri) order */
 void orc_brute_force(const orc_scene*, const float* o3, const float* d3, int64_t n,
                      int32_t* hit_obj, int32_t* hit_tri, float* hit_t_world, int threads);

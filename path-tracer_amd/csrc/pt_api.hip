@@ -170,7 +170,7 @@ int pt_create(int device_id, pt_ctx** out) {
     c->own_stream = true;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount;
-    c->extend_variant = 2;   // 64-thread workgroups, 16 LDS stack entries, wave-shaped trip (tools/extend_ab.py)
+    c->extend_variant = 1;   // 64-thread workgroups, 16 LDS stack entries: 8 waves/SIMD (tools/extend_ab.py)
     if (const char* v = getenv("PT_EXTEND_VARIANT")) c->extend_variant = atoi(v);
     *out = c;
     return PT_OK;
@@ -433,7 +433,9 @@ int pt_render_run(pt_ctx* c, int64_t max_steps, int flags, pt_run_stats* out) {
         out->steps = h.first_empty_step >= 0 ? h.first_empty_step + 1 : h.step_index;
         out->total_rays = h.total_rays; out->total_samples = h.total_samples; out->stack_overflows = (int64_t)h.overflow;
         out->extend_ms = extend_ms; out->extend_launches = launches;
-        out->traversal_bytes = count ? (int64_t)(44 * h.total_rays + 64 * h.visits[0] + 48 * h.visits[1] + 128 * (h.visits[2] + h.visits[3])) : 0;
+        unsigned long long v[4] = {0, 0, 0, 0};
+        for (int sl = 0; sl < 64; sl++) for (int k = 0; k < 4; k++) v[k] += h.visits[sl][k];
+        out->traversal_bytes = count ? (int64_t)(44 * h.total_rays + 64 * v[0] + 48 * v[1] + 128 * (v[2] + v[3])) : 0;
     }
     return PT_OK;
 }

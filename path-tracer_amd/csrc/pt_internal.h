@@ -46,7 +46,8 @@ struct StepHeader {
     int64_t  total_rays;
     int64_t  total_samples;
     unsigned long long overflow; // rays stopped by the stack / iteration guards
-    unsigned long long visits[4];// n_inner, n_leaf, n_enter, n_leave (counting variant only)
+    unsigned long long visits[64][4];   // n_inner, n_leaf, n_enter, n_leave (counting variant only), spread over 64 slots
+                                        // so that one word does not serialise every wave's atomic; summed by the host
     int32_t  blocks_done, pad;   // arrival counter of the logic workgroups (the last one runs the scan)
     int32_t  step_index, work_counter;   // work_counter: next ray-queue entry for the persistent extend kernel
 };

@@ -133,62 +133,6 @@ __device__ __forceinline__ void trav_finish(const SceneView& sc, Ray& r) {
     }
 }
 
-// The same trip written for the wave: one pop site shared by the triangle and the "both children missed"
-// cases, selects instead of nested branches for the child choice, and a wave-uniform test that keeps the whole
-// wave on LDS-only stack code while no lane is deeper than the LDS share.  Entering an object returns to the
-// caller like the reference's loop does; per-ray operation order, and therefore every result, is unchanged.
-template <bool COUNT, class STK, int LDS_N, int BLOCK>
-__device__ __forceinline__ bool trav_step2(const SceneView& sc, Ray& r, const STK& stk, int* lds) {
-    if (++r.iter > PT_MAX_ITERS) { r.overflow = 1; return false; }
-    if (r.sp < r.switch_pt) {                                   // scene.js:330-355
-        const float4* ob = sc.objects + 8 * (int64_t)r.obj;
-        switch_space(ob[0], ob[1], ob[2], r);
-        r.switch_pt = -1; r.obj = -1;
-        if (COUNT) r.n_leave++;
-    }
-    bool pop, push = false; int nxt = 0, far = 0;
-    if (r.node < 0) {
-        if (r.obj < 0) {                                        // scene.js:357-379
-            r.obj = -(r.node + 1);
-            const float4* ob = sc.objects + 8 * (int64_t)r.obj;
-            r.node = __float_as_int(ob[3].x); r.switch_pt = r.sp;
-            switch_space(ob[4], ob[5], ob[6], r);
-            if (COUNT) r.n_enter++;
-            return true;
-        }
-        int t = -(r.node + 1);                                  // scene.js:380-391
-        const float4* tr = sc.tris + 3 * (int64_t)t;
-        float dist = tri_hit(r.o, r.d, tr[0], tr[1], tr[2]);
-        if (dist > 0.0f && dist < r.hit_dist) { r.hit_dist = dist; r.hit_tri = t; r.hit_obj = r.obj; }
-        if (COUNT) r.n_leaf++;
-        pop = true;
-    } else {                                                    // scene.js:392-439
-        const float4* nd = (r.obj < 0 ? sc.tlas : sc.blas) + 4 * (int64_t)r.node;
-        float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
-        if (COUNT) r.n_inner++;
-        float l_dist = slab(F3(q0), F3(q1), r.o, r.id), r_dist = slab(F3(q2), F3(q3), r.o, r.id);
-        bool l_valid = l_dist != -1e30f && l_dist < r.hit_dist;
-        bool r_valid = r_dist != -1e30f && r_dist < r.hit_dist;
-        int l_child = __float_as_int(q0.w), r_child = __float_as_int(q2.w);
-        bool l_first = l_dist < r_dist;
-        push = l_valid && r_valid;
-        pop = !(l_valid || r_valid);
-        bool take_l = push ? l_first : l_valid;
-        nxt = take_l ? l_child : r_child;
-        far = l_first ? r_child : l_child;
-    }
-    if (push && r.sp >= PT_STACK_SIZE) { r.overflow = 1; return false; }
-    if (__all(r.sp < LDS_N)) {                                  // wave-uniform: nobody touches the spill this trip
-        if (push) { lds[r.sp * BLOCK] = far; r.sp += 1; }
-        if (pop) { r.sp -= 1; if (r.sp < 0) return false; nxt = lds[r.sp * BLOCK]; }
-    } else {
-        if (push) { stk.put(r.sp, far); r.sp += 1; }
-        if (pop) { r.sp -= 1; if (r.sp < 0) return false; nxt = stk.get(r.sp); }
-    }
-    r.node = nxt;
-    return true;
-}
-
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
     return v;
@@ -200,15 +144,17 @@ __device__ __forceinline__ void publish(unsigned long long ov, unsigned long lon
     if (__any(ov != 0)) { ov = wave_sum(ov); if (lane_id() == 0) atomicAdd(&hdr->overflow, ov); }
     if (COUNT) {
         a = wave_sum(a); b = wave_sum(b); c = wave_sum(c); e = wave_sum(e);
-        if (lane_id() == 0) { atomicAdd(&hdr->visits[0], a); atomicAdd(&hdr->visits[1], b); atomicAdd(&hdr->visits[2], c); atomicAdd(&hdr->visits[3], e); }
+        if (lane_id() == 0) {
+            unsigned long long* v = hdr->visits[(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & 63];
+            atomicAdd(v + 0, a); atomicAdd(v + 1, b); atomicAdd(v + 2, c); atomicAdd(v + 3, e);
+        }
     }
 }
 
 // --------------------------------------------------------------------------------------------
 // The extend kernel: one launch thread per ray-queue entry (the reference's mapping, ray-trace.js:55-60).
-// STEP selects the trip implementation (1 = literal state machine, 2 = wave-shaped trip).
 // --------------------------------------------------------------------------------------------
-template <int LDS_N, int BLOCK, bool COUNT, int STEP>
+template <int LDS_N, int BLOCK, bool COUNT>
 __global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView sc, StepHeader* hdr, const int32_t* __restrict__ cam_q,
                                                         const int32_t* __restrict__ mat_q, int32_t* spill, int64_t spill_stride) {
     __shared__ int s_stack[LDS_N * BLOCK];
@@ -219,8 +165,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView 
         int path = q < n_cam ? cam_q[q] : mat_q[q - n_cam];
         ray_init(r, F3(ps.path_o[path]), F3(ps.path_d[path]));
         Stack<LDS_N, BLOCK> stk{s_stack + threadIdx.x, spill + q, spill_stride};
-        if (STEP == 1) { while (trav_step<COUNT>(sc, r, stk)) {} }
-        else           { while (trav_step2<COUNT, Stack<LDS_N, BLOCK>, LDS_N, BLOCK>(sc, r, stk, s_stack + threadIdx.x)) {} }
+        while (trav_step<COUNT>(sc, r, stk)) {}
         trav_finish<COUNT>(sc, r);
         ps.hit_obj[path] = r.hit_obj; ps.hit_tri[path] = r.hit_tri;
     }
@@ -253,28 +198,28 @@ static int64_t pad_to(int64_t n, int64_t m) { return (n + m - 1) / m * m; }
 // The spill is sized for the smallest LDS share any variant uses (16 entries) and the largest slot count.
 size_t ptk_spill_ints(int64_t n_rays) { return (size_t)pad_to(n_rays, 256) * (PT_STACK_SIZE - 16); }
 
-template <int LDS_N, int BLOCK, int STEP>
+template <int LDS_N, int BLOCK>
 static void launch_queue(const PathState& ps, int num_paths, const SceneView& sc, StepHeader* hdr, const int32_t* cam_q,
                          const int32_t* mat_q, int32_t* spill, int count, hipStream_t s) {
     int64_t stride = pad_to(num_paths, 256);
     dim3 grid((unsigned)((num_paths + BLOCK - 1) / BLOCK));
-    if (count) hipLaunchKernelGGL((k_extend_queue<LDS_N, BLOCK, true, STEP>), grid, dim3(BLOCK), 0, s, ps, sc, hdr, cam_q, mat_q, spill, stride);
-    else       hipLaunchKernelGGL((k_extend_queue<LDS_N, BLOCK, false, STEP>), grid, dim3(BLOCK), 0, s, ps, sc, hdr, cam_q, mat_q, spill, stride);
+    if (count) hipLaunchKernelGGL((k_extend_queue<LDS_N, BLOCK, true>), grid, dim3(BLOCK), 0, s, ps, sc, hdr, cam_q, mat_q, spill, stride);
+    else       hipLaunchKernelGGL((k_extend_queue<LDS_N, BLOCK, false>), grid, dim3(BLOCK), 0, s, ps, sc, hdr, cam_q, mat_q, spill, stride);
 }
 
-static const char* kVariantNames[] = {"b256 lds24 literal trip", "b64 lds16 literal trip", "b64 lds16 wave-shaped trip", "b256 lds16 wave-shaped trip"};
-int ptk_extend_num_variants() { return 4; }
-const char* ptk_extend_variant_name(int v) { return (v >= 0 && v < 4) ? kVariantNames[v] : "?"; }
+// Variants differ in workgroup size and in how much of the stack is in LDS (occupancy); results are identical.
+// Measured and dropped (profiles/r01_extend_ab_*): persistent waves with lane refill (1.2-3x slower: rays at different
+// depths in one wave lose coherence, and at full occupancy a wave only ever sees two batches), Morton-sorting the queue
+// by ray origin (sort costs more than it saves), a branch-light "wave-shaped" trip and packed-f32 slab math (no change:
+// the trip is bound by the four divergent 16-B node loads per lane, not by VALU count).
+static const char* kVariantNames[] = {"256-thread workgroups, 24 LDS stack entries", "64-thread workgroups, 16 LDS stack entries"};
+int ptk_extend_num_variants() { return 2; }
+const char* ptk_extend_variant_name(int v) { return (v >= 0 && v < 2) ? kVariantNames[v] : "?"; }
 void ptk_extend_queue(const PathState& ps, const RenderConst& rc, const SceneView& sc, StepHeader* hdr, const int32_t* cam_q,
                       const int32_t* mat_q, int32_t* spill, int count, int variant, int n_cus, hipStream_t s) {
-    int np = rc.num_paths; (void)n_cus;
-    switch (variant) {
-        case 0: launch_queue<24, 256, 1>(ps, np, sc, hdr, cam_q, mat_q, spill, count, s); break;
-        case 1: launch_queue<16, 64, 1>(ps, np, sc, hdr, cam_q, mat_q, spill, count, s); break;
-        default:
-        case 2: launch_queue<16, 64, 2>(ps, np, sc, hdr, cam_q, mat_q, spill, count, s); break;
-        case 3: launch_queue<16, 256, 2>(ps, np, sc, hdr, cam_q, mat_q, spill, count, s); break;
-    }
+    (void)n_cus;
+    if (variant == 0) launch_queue<24, 256>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, s);
+    else              launch_queue<16, 64>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, s);
 }
 void ptk_extend_direct(const SceneView& sc, const float4* o4, const float4* d4, int n, int32_t* hit_obj, int32_t* hit_tri,
                        float* hit_dist, int4* counts4, int32_t* spill, StepHeader* hdr, hipStream_t s) {

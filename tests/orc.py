@@ -47,6 +47,7 @@ def lib():
             "orc_scene_blas_nodes": (vp, [vp]), "orc_scene_blas_tris": (vp, [vp]), "orc_scene_tlas_nodes": (vp, [vp]),
             "orc_scene_objects": (vp, [vp]), "orc_scene_tlas_perm": (vp, [vp]), "orc_scene_mesh_perm": (vp, [vp, i32]),
             "orc_trace_rays": (i64, [vp, vp, vp, i64, vp, vp, vp, vp, i32]),
+            "orc_trace_max_depth": (i32, []),
             "orc_brute_force": (None, [vp, vp, vp, i64, vp, vp, vp, i32]),
             "orc_render_create": (vp, [vp, C.POINTER(OrcRenderParams)]), "orc_render_destroy": (None, [vp]),
             "orc_render_step": (None, [vp, C.POINTER(OrcStepStats), i32]),
@@ -131,6 +132,7 @@ class OrcScene:
         cn = np.empty((n, 4), np.int32) if counts else None
         ov = lib().orc_trace_rays(self.h, _p(o), _p(d), n, _p(ho), _p(ht), _p(hd), _p(cn) if counts else None, threads)
         self.last_overflow = ov
+        self.last_max_depth = lib().orc_trace_max_depth()
         return (ho, ht, hd, cn) if counts else (ho, ht, hd)
 
     def brute_force(self, o, d, threads=THREADS):

@@ -250,3 +250,41 @@ def test_full_size_10m_triangle_scene(pta, orc, device):
         np.testing.assert_array_equal(pt.field("path_d").view(np.uint32)[:, :3], orr.field("path_d").view(np.uint32)[:, :3])
     assert pt.field("pixel_counter")[0] == orr.field("pixel_counter")[0]
     np.testing.assert_array_equal(pt.read_image()[..., 3], orr.image()[..., 3])
+
+
+def test_deep_stack_uses_the_hbm_spill(pta, orc, device):
+    """150,000 nearly coincident triangles.  Rays through the empty half of their common bounding box enter every
+    box and hit nothing, so nothing is pruned and the near-first walk keeps one pending entry per tree level: the
+    stack grows past the 16 entries held in LDS (the oracle reports the depth) and the HBM spill is exercised.
+    Hits, distances and visit counts must still match the oracle bit for bit."""
+    rng = np.random.default_rng(21)
+    n = 150_000
+    base = np.array([[-1, -1, 0], [1, -1, 0], [0, 1, 0]], np.float32)
+    v = (base[None] + rng.uniform(-1e-3, 1e-3, (n, 3, 3)).astype(np.float32)).reshape(-1, 3)
+    v[:, 2] += np.repeat(np.linspace(0, 0.5, n, dtype=np.float32), 3)
+    mesh = pta.scenes.mesh_from_vertices(v, np.arange(3 * n).reshape(-1, 3))
+    desc = {"meshes": [mesh], "instances": [(0, [0, 0, 0], [0, 0, 0], [1, 1, 1], 0)], "camera": None}
+    s = pta.scenes.populate(pta.init_scene(device), desc); s.build()
+    o = orc.OrcScene(desc)
+    np.testing.assert_array_equal(s.blas_nodes()[:, NODE_COLS], o.blas_nodes()[:, NODE_COLS])
+    k = 192
+    miss = np.concatenate([rng.uniform(-0.85, -0.75, (k, 1)), rng.uniform(0.75, 0.85, (k, 1)), np.full((k, 1), 3.0)], axis=1)
+    hit = np.concatenate([rng.uniform(-0.3, 0.3, (k, 2)), np.full((k, 1), 3.0)], axis=1)
+    ro = np.concatenate([miss, hit]).astype(np.float32)
+    rd = np.tile(np.float32([0, 0, -1]), (2 * k, 1))
+    g = s.trace_rays(ro, rd, counts=True); c = o.trace_rays(ro, rd, counts=True, threads=16)
+    assert o.last_overflow == 0 and o.last_max_depth > 16, o.last_max_depth
+    np.testing.assert_array_equal(g[0], c[0]); np.testing.assert_array_equal(g[1], c[1])
+    np.testing.assert_array_equal(g[2].view(np.uint32), c[2].view(np.uint32)); np.testing.assert_array_equal(g[3], c[3])
+    assert np.all(c[0][:k] == -1) and np.all(c[0][k:] == 0) and c[3][:k, 0].min() > 100_000
+    # the same geometry through the render path's extend kernel (64-thread workgroups, 16 LDS entries): a camera in
+    # the empty corner looking straight down
+    cam = {"position": [-0.8, 0.8, 3], "lookAt": [-0.8, 0.8001, 0], "fov": 0.5}
+    pt = pta.init_path_tracer({"device": device, "scene": s, "image": {"width": 16, "height": 16}, "camera": cam, "settings": {"samples": 8, "numPaths": 256}})
+    orr = orc.OrcRender(o, 16, 16, cam, 8, 256)
+    for _ in range(2):
+        gs = pt.step(); cs = orr.step(threads=16)
+        assert gs.n_rays == cs.n_rays
+        np.testing.assert_array_equal(pt.field("hit_tri"), orr.field("hit_tri"))
+    rs = pt.run(max_steps=2, count_bytes=True)
+    assert rs.stack_overflows == 0 and rs.traversal_bytes > 256 * 64 * 100_000
