@@ -147,6 +147,9 @@ int pt_set_extend_variant(pt_ctx* ctx, int variant);      /* also: environment P
 /* Re-run the extend kernel `reps` times on the ray queue of the last step (idempotent) and report its mean
  * duration in microseconds: A/B of variants on identical work inside one process. */
 int pt_extend_replay(pt_ctx* ctx, int variant, int reps, double* avg_us);
+/* One more replay of `variant` in which every wave logs 4 x uint64: {start, end} in 100 MHz ticks, XCC_ID << 32 | HW_ID,
+ * block << 32 | class << 24 | trips (class 0 camera, 1 bounce).  out: cap_waves * 4 uint64.  tools/wave_timeline.py */
+int pt_extend_wave_log(pt_ctx* ctx, int variant, uint64_t* out, int64_t cap_waves, int64_t* n_waves);
 
 /* ---- display (scripts/display) ---- */
 /* replaces: initDisplay().draw() fragment shader (display.js:98-113) + canvas unorm8 store.

@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpt_amd.so")
+LIB_PATH = os.environ.get("PT_AMD_LIB") or os.path.join(_HERE, "libpt_amd.so")   # override: A/B of two builds
 
 PT_RUN_TIME_EXTEND = 1
 PT_RUN_COUNT_BYTES = 2
@@ -66,6 +66,7 @@ SIGNATURES = {
     "pt_extend_variants": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]),
     "pt_set_extend_variant": (C.c_int, [C.c_void_p, C.c_int]),
     "pt_extend_replay": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "pt_extend_wave_log": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "pt_tonemap_rgba8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
 }
 

@@ -135,7 +135,7 @@ void enqueue_step(pt_ctx* c, int count_visits, hipEvent_t ev0, hipEvent_t ev1) {
     ptk_compact(c->ps, c->rc, c->d_code, c->d_blk_offsets, c->d_hdr, c->d_cam_q, c->d_mat_q, c->stream);
     ptk_generate_shade(c->ps, c->rc, sv, c->d_hdr, c->d_cam_q, c->d_mat_q, c->stream);
     if (ev0) (void)hipEventRecord(ev0, c->stream);
-    ptk_extend_queue(c->ps, c->rc, sv, c->d_hdr, c->d_cam_q, c->d_mat_q, c->d_spill, count_visits, c->extend_variant, c->n_cus, c->stream);
+    ptk_extend_queue(c->ps, c->rc, sv, c->d_hdr, c->d_cam_q, c->d_mat_q, c->d_spill, count_visits, c->extend_variant, nullptr, c->stream);
     if (ev1) (void)hipEventRecord(ev1, c->stream);
     c->step++;
 }
@@ -170,7 +170,7 @@ int pt_create(int device_id, pt_ctx** out) {
     c->own_stream = true;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount;
-    c->extend_variant = 1;   // 64-thread workgroups, 16 LDS stack entries: 8 waves/SIMD (tools/extend_ab.py)
+    c->extend_variant = 2;   // 64-thread workgroups, 16 LDS stack entries (8 waves/SIMD), longer ray class first (tools/extend_ab.py)
     if (const char* v = getenv("PT_EXTEND_VARIANT")) c->extend_variant = atoi(v);
     *out = c;
     return PT_OK;
@@ -507,7 +507,7 @@ int pt_extend_replay(pt_ctx* c, int variant, int reps, double* avg_us) {
     for (int i = 0; i < reps; i++) {   // the kernel only reads path_o/path_d and rewrites the same hit_obj/hit_tri: idempotent
         HIPOK(c, hipMemsetAsync(&c->d_hdr->work_counter, 0, 4, c->stream));
         HIPOK(c, hipEventRecord(e0, c->stream));
-        ptk_extend_queue(c->ps, c->rc, sv, c->d_hdr, c->d_cam_q, c->d_mat_q, c->d_spill, 0, variant, c->n_cus, c->stream);
+        ptk_extend_queue(c->ps, c->rc, sv, c->d_hdr, c->d_cam_q, c->d_mat_q, c->d_spill, 0, variant, nullptr, c->stream);
         HIPOK(c, hipEventRecord(e1, c->stream));
         HIPOK(c, hipEventSynchronize(e1));
         float ms = 0; HIPOK(c, hipEventElapsedTime(&ms, e0, e1)); total_ms += ms;
@@ -516,6 +516,23 @@ int pt_extend_replay(pt_ctx* c, int variant, int reps, double* avg_us) {
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     *avg_us = total_ms * 1e3 / reps;
     return PT_OK;
+}
+
+int pt_extend_wave_log(pt_ctx* c, int variant, uint64_t* out, int64_t cap_waves, int64_t* n_waves) {
+    if (!c || !out || !n_waves || variant < 0 || variant >= ptk_extend_num_variants()) return fail(c, PT_ERR_ARG, "pt_extend_wave_log: bad argument");
+    if (!c->render_ready || c->step == 0) return fail(c, PT_ERR_STATE, "pt_extend_wave_log: take at least one step first");
+    HIPOK(c, hipSetDevice(c->device));
+    int64_t n = ptk_extend_waves(c->rc.num_paths, variant);
+    if (n > cap_waves) return fail(c, PT_ERR_ARG, "pt_extend_wave_log: buffer too small");
+    unsigned long long* d_log = nullptr; int r;
+    if ((r = dalloc(c, &d_log, (size_t)n * 4, true))) return r;
+    SceneView sv = scene_view(c);
+    ptk_extend_queue(c->ps, c->rc, sv, c->d_hdr, c->d_cam_q, c->d_mat_q, c->d_spill, 0, variant, d_log, c->stream);
+    HIPOK(c, hipGetLastError());
+    r = read_back(c, out, d_log, (size_t)n * 32);
+    dfree(d_log);
+    *n_waves = n;
+    return r;
 }
 
 // ---------------------------------------------------------------------------------------- display

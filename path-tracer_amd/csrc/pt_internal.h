@@ -50,6 +50,10 @@ struct StepHeader {
                                         // so that one word does not serialise every wave's atomic; summed by the host
     int32_t  blocks_done, pad;   // arrival counter of the logic workgroups (the last one runs the scan)
     int32_t  step_index, work_counter;   // work_counter: next ray-queue entry for the persistent extend kernel
+    // Dispatch order of the extend kernel (performance only, results do not depend on it): sampled waves report their trip
+    // count (the longest lane's) per ray class, the scan of the next step puts the class that held the longest wave first.
+    uint32_t cls_max[32][2];             // {camera, bounce} maximum trips of a wave, spread over 32 cells
+    int32_t  extend_order, pad2;         // 0 = camera rays first (queue order), 1 = bounce rays first
 };
 
 struct RenderConst {
@@ -80,7 +84,9 @@ void ptk_generate_shade(const PathState& ps, const RenderConst& rc, const SceneV
                         const int32_t* cam_q, const int32_t* mat_q, hipStream_t s);
 // Extend over the step's ray queue (camera ++ material).  count != 0 selects the visit-counting variant.
 void ptk_extend_queue(const PathState& ps, const RenderConst& rc, const SceneView& sc, StepHeader* hdr,
-                      const int32_t* cam_q, const int32_t* mat_q, int32_t* spill, int count, int variant, int n_cus, hipStream_t s);
+                      const int32_t* cam_q, const int32_t* mat_q, int32_t* spill, int count, int variant,
+                      unsigned long long* wave_log /* null unless measuring */, hipStream_t s);
+int64_t ptk_extend_waves(int num_paths, int variant);   // waves the launch of that variant holds (wave_log entries)
 int ptk_extend_num_variants();
 const char* ptk_extend_variant_name(int v);
 // Extend over n caller rays (o4/d4: float4 per ray).  counts4 (int4 per ray) may be null.

@@ -154,12 +154,23 @@ __device__ __forceinline__ void publish(unsigned long long ov, unsigned long lon
 // --------------------------------------------------------------------------------------------
 // The extend kernel: one launch thread per ray-queue entry (the reference's mapping, ray-trace.js:55-60).
 // --------------------------------------------------------------------------------------------
-template <int LDS_N, int BLOCK, bool COUNT>
+// LOG (measurement only, tools/wave_timeline.py): every wave records {start, end} in 100 MHz ticks, where it ran and how
+// many trips it took -- wave_log[4 * wave] = {t0, t1, XCC_ID << 32 | HW_ID, block << 32 | class << 24 | trips}.
+template <int LDS_N, int BLOCK, bool COUNT, int ORDER, bool LOG>
 __global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView sc, StepHeader* hdr, const int32_t* __restrict__ cam_q,
-                                                        const int32_t* __restrict__ mat_q, int32_t* spill, int64_t spill_stride) {
+                                                        const int32_t* __restrict__ mat_q, int32_t* spill, int64_t spill_stride,
+                                                        unsigned long long* wave_log) {
+    unsigned long long t_start = LOG ? wall_clock64() : 0;
     __shared__ int s_stack[LDS_N * BLOCK];
-    int q = blockIdx.x * BLOCK + threadIdx.x;
     int n_cam = hdr->n_camera, n_rays = n_cam + hdr->n_material;
+    // ORDER 2: a launch lasts as long as its longest wave plus the time that wave waited to start
+    // (profiles/r01_wave_timeline_*), so the class of rays that held the longest wave in the previous step is dispatched
+    // first: queue order when that was a camera wave, reversed when it was a bounce wave (k_scan decides).
+    int nblk = (n_rays + BLOCK - 1) / BLOCK;
+    int blk = (ORDER == 2 && hdr->extend_order) ? nblk - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    if (blk < 0 || blk >= nblk) return;
+    if (LOG && lane_id() == 0) wave_log[4 * (int64_t)(blockIdx.x * (BLOCK >> 6) + (threadIdx.x >> 6)) + 1] = 0;
+    int q = blk * BLOCK + threadIdx.x;
     Ray r; ray_init(r, F3(0, 0, 1), F3(0, 0, 1));
     if (q < n_rays) {
         int path = q < n_cam ? cam_q[q] : mat_q[q - n_cam];
@@ -170,6 +181,24 @@ __global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView 
         ps.hit_obj[path] = r.hit_obj; ps.hit_tri[path] = r.hit_tri;
     }
     publish<COUNT>(r.overflow, r.n_inner, r.n_leaf, r.n_enter, r.n_leave, hdr);
+    if (LOG) {
+        int trips = r.iter;
+        for (int off = 32; off > 0; off >>= 1) trips = max(trips, __shfl_xor(trips, off));
+        if (lane_id() == 0) {
+            unsigned long long* w = wave_log + 4 * (int64_t)(blockIdx.x * (BLOCK >> 6) + (threadIdx.x >> 6));
+            unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20), hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+            w[0] = t_start; w[1] = wall_clock64(); w[2] = ((unsigned long long)xcc << 32) | hw;
+            w[3] = ((unsigned long long)blk << 32) | ((q < n_cam ? 0ull : 1ull) << 24) | (unsigned)min(trips, 0xffffff);
+        }
+    }
+    if (ORDER == 2 && blockIdx.x % 5 == 0) {     // one workgroup in five (all XCDs) reports its waves' trip counts
+        int trips = r.iter;
+        for (int off = 32; off > 0; off >>= 1) trips = max(trips, __shfl_xor(trips, off));
+        if (lane_id() == 0) {
+            unsigned* cell = &hdr->cls_max[(blockIdx.x / 5 * (BLOCK >> 6) + (threadIdx.x >> 6)) & 31][q < n_cam ? 0 : 1];
+            if ((unsigned)trips > *cell) atomicMax(cell, (unsigned)trips);   // rarely taken once the maximum has settled
+        }
+    }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -198,28 +227,42 @@ static int64_t pad_to(int64_t n, int64_t m) { return (n + m - 1) / m * m; }
 // The spill is sized for the smallest LDS share any variant uses (16 entries) and the largest slot count.
 size_t ptk_spill_ints(int64_t n_rays) { return (size_t)pad_to(n_rays, 256) * (PT_STACK_SIZE - 16); }
 
-template <int LDS_N, int BLOCK>
+template <int LDS_N, int BLOCK, int ORDER>
 static void launch_queue(const PathState& ps, int num_paths, const SceneView& sc, StepHeader* hdr, const int32_t* cam_q,
-                         const int32_t* mat_q, int32_t* spill, int count, hipStream_t s) {
+                         const int32_t* mat_q, int32_t* spill, int count, unsigned long long* wave_log, hipStream_t s) {
     int64_t stride = pad_to(num_paths, 256);
     dim3 grid((unsigned)((num_paths + BLOCK - 1) / BLOCK));
-    if (count) hipLaunchKernelGGL((k_extend_queue<LDS_N, BLOCK, true>), grid, dim3(BLOCK), 0, s, ps, sc, hdr, cam_q, mat_q, spill, stride);
-    else       hipLaunchKernelGGL((k_extend_queue<LDS_N, BLOCK, false>), grid, dim3(BLOCK), 0, s, ps, sc, hdr, cam_q, mat_q, spill, stride);
+    if (wave_log)   hipLaunchKernelGGL((k_extend_queue<LDS_N, BLOCK, false, ORDER, true>), grid, dim3(BLOCK), 0, s, ps, sc, hdr, cam_q, mat_q, spill, stride, wave_log);
+    else if (count) hipLaunchKernelGGL((k_extend_queue<LDS_N, BLOCK, true, ORDER, false>), grid, dim3(BLOCK), 0, s, ps, sc, hdr, cam_q, mat_q, spill, stride, wave_log);
+    else            hipLaunchKernelGGL((k_extend_queue<LDS_N, BLOCK, false, ORDER, false>), grid, dim3(BLOCK), 0, s, ps, sc, hdr, cam_q, mat_q, spill, stride, wave_log);
 }
 
 // Variants differ in workgroup size and in how much of the stack is in LDS (occupancy); results are identical.
 // Measured and dropped (profiles/r01_extend_ab_*): persistent waves with lane refill (1.2-3x slower: rays at different
 // depths in one wave lose coherence, and at full occupancy a wave only ever sees two batches), Morton-sorting the queue
-// by ray origin (sort costs more than it saves), a branch-light "wave-shaped" trip and packed-f32 slab math (no change:
-// the trip is bound by the four divergent 16-B node loads per lane, not by VALU count).
-static const char* kVariantNames[] = {"256-thread workgroups, 24 LDS stack entries", "64-thread workgroups, 16 LDS stack entries"};
-int ptk_extend_num_variants() { return 2; }
-const char* ptk_extend_variant_name(int v) { return (v >= 0 && v < 2) ? kVariantNames[v] : "?"; }
+// by ray origin (sort costs more than it saves), one memory wait per trip (all lanes classify, issue their four loads
+// together and share the switch code; leaving becomes a trip of its own: 6-9 % slower, profiles/r01_extend_ab_*_v6_*), a branch-light "wave-shaped" trip and packed-f32 slab math (no change:
+// the trip is bound by the four divergent 16-B node loads per lane, not by VALU count), one shared object-space switch
+// site per trip with enter + root test in the same trip (5-6 % slower: the longer dependent chain per trip costs more than
+// the shorter code saves; with the final leave inside the loop 27 % slower, because lanes then finish one by one).
+// Dispatch order (variant 2) is the one change that paid: always-reversed order gains 12-22 % on Cornell and the instanced
+// scene and loses 10-15 % on the single-mesh scene; choosing by mean trips picks wrong there; raising the priority of
+// waves past 12 trips changes nothing (profiles/r01_extend_ab_*_v7_*).
+// Sensitivity bound: replacing every correctly rounded divide by a bare v_rcp (results no longer exact) gains 7 % on
+// Cornell and 4 % on the 82 k-triangle mesh, so a cheaper exact divide could return at most half of that.
+static const char* kVariantNames[] = {"256-thread workgroups, 24 LDS stack entries", "64-thread workgroups, 16 LDS stack entries",
+                                      "64-thread workgroups, 16 LDS entries, class of the longest wave first"};
+int ptk_extend_num_variants() { return 3; }
+const char* ptk_extend_variant_name(int v) { return (v >= 0 && v < 3) ? kVariantNames[v] : "?"; }
 void ptk_extend_queue(const PathState& ps, const RenderConst& rc, const SceneView& sc, StepHeader* hdr, const int32_t* cam_q,
-                      const int32_t* mat_q, int32_t* spill, int count, int variant, int n_cus, hipStream_t s) {
-    (void)n_cus;
-    if (variant == 0) launch_queue<24, 256>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, s);
-    else              launch_queue<16, 64>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, s);
+                      const int32_t* mat_q, int32_t* spill, int count, int variant, unsigned long long* wave_log, hipStream_t s) {
+    if (variant == 0)      launch_queue<24, 256, 1>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, s);
+    else if (variant == 1) launch_queue<16, 64, 1>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, s);
+    else                   launch_queue<16, 64, 2>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, s);
+}
+int64_t ptk_extend_waves(int num_paths, int variant) {
+    int block = variant == 0 ? 256 : 64;
+    return (int64_t)((num_paths + block - 1) / block) * (block / 64);
 }
 void ptk_extend_direct(const SceneView& sc, const float4* o4, const float4* d4, int n, int32_t* hit_obj, int32_t* hit_tri,
                        float* hit_dist, int4* counts4, int32_t* spill, StepHeader* hdr, hipStream_t s) {

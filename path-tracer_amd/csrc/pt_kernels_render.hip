@@ -51,6 +51,14 @@ __device__ void scan_blocks(const int4* blk_counts, int4* blk_offsets, int nbloc
         hdr->step_index += 1;
         hdr->work_counter = 0;
     }
+    if (wave == 0) {   // longest-waves-first dispatch order for the next extend launch (see StepHeader::cls_cost)
+        unsigned* cell = &hdr->cls_max[lane >> 1][lane & 1];
+        unsigned v = *cell;
+        *cell = 0;
+        for (int off = 2; off < 64; off <<= 1) v = max(v, (unsigned)__shfl_xor((int)v, off));
+        unsigned cam = __shfl((int)v, 0), mat = __shfl((int)v, 1);
+        if (lane == 0) hdr->extend_order = mat > cam ? 1 : 0;
+    }
 }
 
 // ============================================================================================
