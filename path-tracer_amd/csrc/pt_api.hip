@@ -38,7 +38,7 @@ struct pt_ctx {
     // render
     bool render_ready = false; RenderConst rc{}; PathState ps{};
     float* d_image = nullptr; bool own_image = false; uint8_t* d_code = nullptr;
-    int4 *d_blk_counts = nullptr, *d_blk_offsets = nullptr; int32_t *d_cam_q = nullptr, *d_mat_q = nullptr, *d_spill = nullptr;
+    int4 *d_blk_counts = nullptr; int32_t *d_cam_q = nullptr, *d_mat_q = nullptr, *d_spill = nullptr;
     StepHeader* d_hdr = nullptr; StepHeader* h_hdr = nullptr; int nblocks = 0; int64_t step = 0;
     std::vector<std::pair<void*, size_t>> render_allocs; std::vector<hipEvent_t> events; int64_t ticket_begin = 0;
 };
@@ -131,9 +131,9 @@ int read_back(pt_ctx* c, void* dst, const void* src, size_t bytes) {
 
 void enqueue_step(pt_ctx* c, int count_visits, hipEvent_t ev0, hipEvent_t ev1) {
     SceneView sv = scene_view(c);
-    ptk_logic(c->ps, c->rc, c->step == 0 ? 1 : 0, c->d_image, c->d_code, c->d_blk_counts, c->d_blk_offsets, c->d_hdr, c->stream);
-    ptk_compact(c->ps, c->rc, c->d_code, c->d_blk_offsets, c->d_hdr, c->d_cam_q, c->d_mat_q, c->stream);
-    ptk_generate_shade(c->ps, c->rc, sv, c->d_hdr, c->d_cam_q, c->d_mat_q, c->stream);
+    int parity = (int)(c->step & 1);
+    ptk_logic(c->ps, c->rc, c->step == 0 ? 1 : 0, c->d_image, c->d_code, c->d_blk_counts, c->stream);
+    ptk_compact_generate_shade(c->ps, c->rc, sv, c->d_code, c->d_blk_counts, parity, c->d_hdr, c->d_cam_q, c->d_mat_q, c->stream);
     if (ev0) (void)hipEventRecord(ev0, c->stream);
     ptk_extend_queue(c->ps, c->rc, sv, c->d_hdr, c->d_cam_q, c->d_mat_q, c->d_spill, count_visits, c->extend_variant, nullptr, c->stream);
     if (ev1) (void)hipEventRecord(ev1, c->stream);
@@ -144,7 +144,7 @@ void enqueue_step(pt_ctx* c, int count_visits, hipEvent_t ev0, hipEvent_t ev1) {
 int write_header(pt_ctx* c) {
     HIPOK(c, hipStreamSynchronize(c->stream));
     StepHeader h; memset(&h, 0, sizeof h);
-    h.first_empty_step = -1; h.pixel_counter = c->ticket_begin;
+    h.first_empty_step = -1; h.pixel_counter = c->ticket_begin; h.ticket_next[0] = c->ticket_begin;
     *c->h_hdr = h;
     HIPOK(c, hipMemcpyAsync(c->d_hdr, c->h_hdr, sizeof h, hipMemcpyHostToDevice, c->stream));
     HIPOK(c, hipStreamSynchronize(c->stream));
@@ -364,8 +364,8 @@ int pt_render_init(pt_ctx* c, const pt_render_params* p) {
         (r = ralloc(c, &ps.path_d, n)) || (r = ralloc(c, &ps.hit_obj, n)) || (r = ralloc(c, &ps.hit_tri, n)) || (r = ralloc(c, &ps.flags, n)) ||
         (r = ralloc(c, &ps.samples_in_pixel, n)) || (r = ralloc(c, &ps.ticket_acc, n)))
         return r;
-    c->nblocks = (int)((np + PT_BLOCK - 1) / PT_BLOCK);
-    if ((r = ralloc(c, &c->d_code, n)) || (r = ralloc(c, &c->d_blk_counts, (size_t)c->nblocks)) || (r = ralloc(c, &c->d_blk_offsets, (size_t)c->nblocks)) ||
+    c->nblocks = ptk_step_blocks((int)np);
+    if ((r = ralloc(c, &c->d_code, n)) || (r = ralloc(c, &c->d_blk_counts, (size_t)c->nblocks)) ||
         (r = ralloc(c, &c->d_cam_q, n)) || (r = ralloc(c, &c->d_mat_q, n)) || (r = ralloc(c, &c->d_spill, ptk_spill_ints(np))) ||
         (r = ralloc(c, &c->d_hdr, 1)))
         return r;

@@ -5,6 +5,7 @@
 #include <stddef.h>
 
 #define PT_BLOCK 256                 // threads per workgroup: 4 wave64
+#define PT_STEP_BLOCK 1024           // logic / compaction workgroups: 16 wave64, one count record per 1024 slots
 #define PT_STACK_SIZE 64             // traversal stack entries per ray (reference: 32, scene.js:305)
 #define PT_LDS_STACK 24              // of which the first PT_LDS_STACK live in LDS, the rest in an HBM spill
 #define PT_MAX_ITERS (1 << 20)       // traversal loop guard (degenerate N=1 trees can self-loop)
@@ -43,6 +44,8 @@ struct StepHeader {
     int32_t  n_camera, n_material, n_rays, first_empty_step;   // first_empty_step: -1 until both queues are empty
     int64_t  pixel_counter;      // next ticket to hand out
     int64_t  ticket_base;        // pixel_counter at the start of the current step
+    int64_t  ticket_next[2];     // [step & 1]: first ticket of that step (double-buffered: workgroup 0 of the compaction
+                                 // launch writes the next step's while the other workgroups still read this step's)
     int64_t  total_rays;
     int64_t  total_samples;
     unsigned long long overflow; // rays stopped by the stack / iteration guards
@@ -76,12 +79,11 @@ hipError_t pt_sort_pairs_u32(void* tmp, size_t* tmp_bytes, const uint32_t* kin, 
                              const int32_t* vin, int32_t* vout, size_t n, hipStream_t s);
 
 // ---- launchers (pt_kernels_render.hip) --------------------------------------------------------
-void ptk_logic(const PathState& ps, const RenderConst& rc, int first_sample, float* image, uint8_t* code,
-               int4* blk_counts, int4* blk_offsets, StepHeader* hdr, hipStream_t s);
-void ptk_compact(const PathState& ps, const RenderConst& rc, const uint8_t* code, const int4* blk_offsets,
-                 const StepHeader* hdr, int32_t* cam_q, int32_t* mat_q, hipStream_t s);
-void ptk_generate_shade(const PathState& ps, const RenderConst& rc, const SceneView& sc, const StepHeader* hdr,
-                        const int32_t* cam_q, const int32_t* mat_q, hipStream_t s);
+int  ptk_step_blocks(int num_paths);   // workgroups (= count records) of the two step kernels below
+void ptk_logic(const PathState& ps, const RenderConst& rc, int first_sample, float* image, uint8_t* code, int4* blk_counts, hipStream_t s);
+// parity = step & 1 (StepHeader::ticket_next)
+void ptk_compact_generate_shade(const PathState& ps, const RenderConst& rc, const SceneView& sc, const uint8_t* code, const int4* blk_counts,
+                                int parity, StepHeader* hdr, int32_t* cam_q, int32_t* mat_q, hipStream_t s);
 // Extend over the step's ray queue (camera ++ material).  count != 0 selects the visit-counting variant.
 void ptk_extend_queue(const PathState& ps, const RenderConst& rc, const SceneView& sc, StepHeader* hdr,
                       const int32_t* cam_q, const int32_t* mat_q, int32_t* spill, int count, int variant,

@@ -1,10 +1,11 @@
 // pt_kernels_render.hip -- the wavefront integrator on gfx950 (extend is in pt_kernels_extend.hip).
 //
-// One step() = logic -> scan -> compact -> generate+shade -> extend, all on one stream, no host round trip
-// in between (the reference awaits the queue after each of its four dispatches, path-tracer.js:86-107).
-// Queue appends are order-preserving: wave64 ballots give each lane its rank, one scan over per-workgroup
-// counts gives each workgroup its base, so every queue is in ascending path-slot order and pixel tickets are
-// handed out in slot order (the reference's canonical serial order; its own order is a race,
+// One step() = logic -> compact+generate+shade -> extend: three launches on one stream, no host round trip in
+// between (the reference awaits the queue after each of its four dispatches, path-tracer.js:86-107).  The thread
+// that compacts a slot also produces the slot's next ray: the camera ray as soon as the pixel ticket is known, or
+// the bounce ray (the camera and material kernels only touch their slot's own state).
+// Queue appends are order-preserving: wave64 ballots give each lane its rank, the per-workgroup counts in front of a
+// workgroup give it its base (no scan launch), so every queue is in ascending path-slot order and pixel tickets are handed out in slot order (the reference's canonical serial order; its own order is a race,
 // logic.js:158,168,205,213).  Because every camera-queue and every material-queue entry produces exactly one
 // ray, the ray-trace queue (QueuesStage3.ray_trace_queue) is the concatenation camera ++ material and is
 // never stored.
@@ -21,151 +22,6 @@ __device__ __forceinline__ int rank_below(unsigned long long mask) {   // set bi
     return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
 }
 __device__ __forceinline__ int4 add4(int4 a, int4 b) { return make_int4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-
-// ============================================================================================
-// scan: exclusive prefix over the per-workgroup counts by ONE workgroup (the reference's global atomics,
-// logic.js:163-170,199-219); publishes queue sizes, ticket base and run totals in the StepHeader.
-// ============================================================================================
-__device__ void scan_blocks(const int4* blk_counts, int4* blk_offsets, int nblocks, StepHeader* hdr, int4* s_wave /* [PT_BLOCK/64] */) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int per = (nblocks + PT_BLOCK - 1) / PT_BLOCK, b0 = min(tid * per, nblocks), b1 = min(b0 + per, nblocks);
-    int4 sum = make_int4(0, 0, 0, 0);
-    for (int b = b0; b < b1; b++) sum = add4(sum, blk_counts[b]);
-    int4 inc = sum;
-    for (int off = 1; off < 64; off <<= 1) {   // inclusive scan inside the wave
-        int x = __shfl_up(inc.x, off), y = __shfl_up(inc.y, off), z = __shfl_up(inc.z, off), w = __shfl_up(inc.w, off);
-        if (lane >= off) inc = add4(inc, make_int4(x, y, z, w));
-    }
-    if (lane == 63) s_wave[wave] = inc;
-    __syncthreads();
-    int4 run = make_int4(inc.x - sum.x, inc.y - sum.y, inc.z - sum.z, 0), tot = make_int4(0, 0, 0, 0);
-    for (int w = 0; w < PT_BLOCK / 64; w++) { if (w < wave) run = add4(run, s_wave[w]); tot = add4(tot, s_wave[w]); }
-    for (int b = b0; b < b1; b++) { blk_offsets[b] = make_int4(run.x, run.y, run.z, 0); run = add4(run, blk_counts[b]); }
-    if (tid == 0) {
-        hdr->n_camera = tot.x; hdr->n_material = tot.y; hdr->n_rays = tot.x + tot.y;
-        hdr->ticket_base = hdr->pixel_counter;
-        hdr->pixel_counter += tot.z;
-        hdr->total_rays += (int64_t)tot.x + tot.y;
-        hdr->total_samples += tot.w;
-        if (tot.x + tot.y == 0 && hdr->first_empty_step < 0) hdr->first_empty_step = hdr->step_index;
-        hdr->step_index += 1;
-        hdr->work_counter = 0;
-    }
-    if (wave == 0) {   // longest-waves-first dispatch order for the next extend launch (see StepHeader::cls_cost)
-        unsigned* cell = &hdr->cls_max[lane >> 1][lane & 1];
-        unsigned v = *cell;
-        *cell = 0;
-        for (int off = 2; off < 64; off <<= 1) v = max(v, (unsigned)__shfl_xor((int)v, off));
-        unsigned cam = __shfl((int)v, 0), mat = __shfl((int)v, 1);
-        if (lane == 0) hdr->extend_order = mat > cam ? 1 : 0;
-    }
-}
-
-// ============================================================================================
-// logic (logic.js:62-152): per-slot state machine, image accumulation, decisions
-// ============================================================================================
-// code bits: 1 = camera queue, 2 = material queue, 4 = wants a pixel ticket.
-// blk_counts[b] = {#camera, #material, #tickets, #finished samples} of workgroup b.
-// Image accumulation: a slot owns its pixel for the 8 samples of a ticket (logic.js:6,129), so the samples are
-// summed in the slot's ticket accumulator and reach the image with ONE group of float atomics per ticket instead
-// of one per sample (scattered float atomics are the slowest memory operation on this chip).  The reference's
-// own add order is a race (logic.js:222-233); sample counts stay exact.
-__global__ __launch_bounds__(PT_BLOCK) void k_logic(PathState ps, RenderConst rc, int first_sample, float* __restrict__ image,
-                                                    uint8_t* __restrict__ code_out, int4* __restrict__ blk_counts) {
-    __shared__ int4 s_wave[PT_BLOCK / 64];
-    int i = blockIdx.x * PT_BLOCK + threadIdx.x;
-    unsigned code = 0; bool finished = false;
-    if (i < rc.num_paths && (ps.flags[i] & (1u << 31)) == 0u) {
-        if (first_sample) {
-            uint32_t gi = (uint32_t)(rc.slot_base + i);
-            ps.random_seed[i] = (float)base_hash(gi, gi + 1u) * 2.3283064365386962890625e-10f + 0.008f;   // logic.js:77
-            ps.path_throughput[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-            code = 1u | 4u;
-        } else {
-            f3  tp = F3(ps.path_throughput[i]);
-            int nb = ps.num_bounces[i] + 1;
-            bool b_hit = ps.hit_obj[i] >= 0;
-            uint32_t flags = ps.flags[i];
-            f3 contrib = F3(0.0f, 0.0f, 0.0f);
-            if (flags & 1u) {                                                   // logic.js:94-109
-                tp = tp * F3(ps.material_throughput_pdf[i]);
-                if (nb > 3) {
-                    float seed = ps.random_seed[i];
-                    float2 r2 = rand2(seed);
-                    ps.random_seed[i] = seed + 2.0f;
-                    float q = fmin_(fmax_(0.1f, 1.0f - tp.y), 0.7f);
-                    if (r2.x < q) tp = F3(0.0f, 0.0f, 0.0f); else tp = tp / (1.0f - q);
-                }
-            }
-            if (nb > 20) tp = F3(0.0f, 0.0f, 0.0f);                              // logic.js:111-113
-            if (!b_hit) { contrib = F3(0.0f + 2.0f * tp.x, 0.0f + 2.0f * tp.y, 0.0f + 2.0f * tp.z); tp = F3(0.0f, 0.0f, 0.0f); }
-            if (tp.x == 0.0f && tp.y == 0.0f && tp.z == 0.0f) {                  // logic.js:121-133
-                finished = true; code |= 1u; nb = 0; tp = F3(1.0f, 1.0f, 1.0f);
-                int sip = ps.samples_in_pixel[i];
-                if (sip >= PT_SAMPLES_PER_TICKET - 1) code |= 4u; else ps.samples_in_pixel[i] = sip + 1;
-            } else { code |= 2u; nb += 1; }
-            ps.path_throughput[i] = make_float4(tp.x, tp.y, tp.z, 0.0f);
-            ps.num_bounces[i] = nb;
-            ps.flags[i] = 0u;
-            if (finished) {                                                      // logic.js:145-150
-                float4 acc = ps.ticket_acc[i];
-                acc.x += contrib.x; acc.y += contrib.y; acc.z += contrib.z; acc.w += 1.0f;
-                if (code & 4u) {                                                 // ticket complete: flush to the image
-                    float* px = image + 4 * (int64_t)ps.pixel_index[i];
-                    unsafeAtomicAdd(px + 0, acc.x); unsafeAtomicAdd(px + 1, acc.y);
-                    unsafeAtomicAdd(px + 2, acc.z); unsafeAtomicAdd(px + 3, acc.w);
-                    acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                }
-                ps.ticket_acc[i] = acc;
-            }
-        }
-    }
-    if (i < rc.num_paths) code_out[i] = (uint8_t)code;
-    unsigned long long b_cam = __ballot(code & 1u), b_mat = __ballot(code & 2u), b_tix = __ballot(code & 4u), b_fin = __ballot(finished);
-    if (lane_id() == 0)
-        s_wave[threadIdx.x >> 6] = make_int4(__popcll(b_cam), __popcll(b_mat), __popcll(b_tix), __popcll(b_fin));
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int4 t = s_wave[0];
-        for (int w = 1; w < PT_BLOCK / 64; w++) t = add4(t, s_wave[w]);
-        blk_counts[blockIdx.x] = t;
-    }
-}
-
-// The scan is its own one-workgroup launch.  (Folding it into k_logic as "the last workgroup to arrive scans" was
-// measured: 3907 arrivals on one device-scope counter plus a release fence per workgroup took k_logic from 57 to
-// 155 us -- a kernel boundary costs ~2 us.)
-__global__ __launch_bounds__(PT_BLOCK) void k_scan(const int4* __restrict__ blk_counts, int4* __restrict__ blk_offsets, int nblocks, StepHeader* hdr) {
-    __shared__ int4 s_wave[PT_BLOCK / 64];
-    scan_blocks(blk_counts, blk_offsets, nblocks, hdr, s_wave);
-}
-
-// ============================================================================================
-// compact: stable scatter into the camera / material queues + pixel tickets (logic.js:155-219)
-// ============================================================================================
-__global__ __launch_bounds__(PT_BLOCK) void k_compact(PathState ps, RenderConst rc, const uint8_t* __restrict__ code_in,
-                                                      const int4* __restrict__ blk_offsets, const StepHeader* __restrict__ hdr,
-                                                      int32_t* __restrict__ cam_q, int32_t* __restrict__ mat_q) {
-    __shared__ int4 s_wave[PT_BLOCK / 64];
-    int i = blockIdx.x * PT_BLOCK + threadIdx.x;
-    unsigned code = i < rc.num_paths ? code_in[i] : 0u;
-    unsigned long long b_cam = __ballot(code & 1u), b_mat = __ballot(code & 2u), b_tix = __ballot(code & 4u);
-    int wave = threadIdx.x >> 6;
-    if (lane_id() == 0) s_wave[wave] = make_int4(__popcll(b_cam), __popcll(b_mat), __popcll(b_tix), 0);
-    __syncthreads();
-    int4 off = blk_offsets[blockIdx.x];
-    for (int w = 0; w < wave; w++) { off.x += s_wave[w].x; off.y += s_wave[w].y; off.z += s_wave[w].z; }
-    if (code & 1u) cam_q[off.x + rank_below(b_cam)] = i;
-    if (code & 2u) mat_q[off.y + rank_below(b_mat)] = i;
-    if (code & 4u) {
-        int64_t ticket = hdr->ticket_base + off.z + rank_below(b_tix);
-        if (ticket >= rc.ticket_limit) ps.flags[i] |= (1u << 31);                  // logic.js:177-179
-        else {                                                                      // logic.js:181-182
-            ps.pixel_index[i] = (int32_t)(ticket % ((int64_t)rc.width * rc.height));
-            ps.samples_in_pixel[i] = 0;
-        }
-    }
-}
 
 // ============================================================================================
 // generate (camera.js:60-118)
@@ -237,18 +93,151 @@ __device__ __forceinline__ void shade_one(const PathState& ps, const SceneView& 
     ps.path_d[path] = make_float4(nd.x, nd.y, nd.z, 0.0f);
 }
 
-// generate and shade share one launch: workgroups [0, ceil(n_camera/256)) generate, the following ones shade
-// (every workgroup is all-camera or all-material, so the two bodies never diverge inside a wave).
-__global__ __launch_bounds__(PT_BLOCK) void k_generate_shade(PathState ps, RenderConst rc, SceneView sc, const StepHeader* __restrict__ hdr,
-                                                             const int32_t* __restrict__ cam_q, const int32_t* __restrict__ mat_q) {
-    const int n_cam = hdr->n_camera, cam_blocks = (n_cam + PT_BLOCK - 1) / PT_BLOCK;
-    if ((int)blockIdx.x < cam_blocks) {
-        int q = blockIdx.x * PT_BLOCK + threadIdx.x;
-        if (q < n_cam) generate_one(ps, rc, cam_q[q]);
-    } else {
-        int q = (blockIdx.x - cam_blocks) * PT_BLOCK + threadIdx.x;
-        if (q < hdr->n_material) shade_one(ps, sc, mat_q[q]);
+// ============================================================================================
+// logic (logic.js:62-152): per-slot state machine, image accumulation, decisions
+// ============================================================================================
+// code bits: 1 = camera queue, 2 = material queue, 4 = wants a pixel ticket.
+// blk_counts[b] = {#camera, #material, #tickets, #finished samples} of workgroup b.
+// Image accumulation: a slot owns its pixel for the 8 samples of a ticket (logic.js:6,129), so the samples are
+// summed in the slot's ticket accumulator and reach the image with ONE group of float atomics per ticket instead
+// of one per sample (scattered float atomics are the slowest memory operation on this chip).  The reference's
+// own add order is a race (logic.js:222-233); sample counts stay exact.
+__global__ __launch_bounds__(PT_STEP_BLOCK) void k_logic(PathState ps, RenderConst rc, int first_sample, float* __restrict__ image,
+                                                         uint8_t* __restrict__ code_out, int4* __restrict__ blk_counts) {
+    __shared__ int4 s_wave[PT_STEP_BLOCK / 64];
+    int i = blockIdx.x * PT_STEP_BLOCK + threadIdx.x;
+    unsigned code = 0; bool finished = false;
+    if (i < rc.num_paths && (ps.flags[i] & (1u << 31)) == 0u) {
+        if (first_sample) {
+            uint32_t gi = (uint32_t)(rc.slot_base + i);
+            ps.random_seed[i] = (float)base_hash(gi, gi + 1u) * 2.3283064365386962890625e-10f + 0.008f;   // logic.js:77
+            ps.path_throughput[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+            code = 1u | 4u;
+        } else {
+            f3  tp = F3(ps.path_throughput[i]);
+            int nb = ps.num_bounces[i] + 1;
+            bool b_hit = ps.hit_obj[i] >= 0;
+            uint32_t flags = ps.flags[i];
+            f3 contrib = F3(0.0f, 0.0f, 0.0f);
+            if (flags & 1u) {                                                   // logic.js:94-109
+                tp = tp * F3(ps.material_throughput_pdf[i]);
+                if (nb > 3) {
+                    float seed = ps.random_seed[i];
+                    float2 r2 = rand2(seed);
+                    ps.random_seed[i] = seed + 2.0f;
+                    float q = fmin_(fmax_(0.1f, 1.0f - tp.y), 0.7f);
+                    if (r2.x < q) tp = F3(0.0f, 0.0f, 0.0f); else tp = tp / (1.0f - q);
+                }
+            }
+            if (nb > 20) tp = F3(0.0f, 0.0f, 0.0f);                              // logic.js:111-113
+            if (!b_hit) { contrib = F3(0.0f + 2.0f * tp.x, 0.0f + 2.0f * tp.y, 0.0f + 2.0f * tp.z); tp = F3(0.0f, 0.0f, 0.0f); }
+            if (tp.x == 0.0f && tp.y == 0.0f && tp.z == 0.0f) {                  // logic.js:121-133
+                finished = true; code |= 1u; nb = 0; tp = F3(1.0f, 1.0f, 1.0f);
+                int sip = ps.samples_in_pixel[i];
+                if (sip >= PT_SAMPLES_PER_TICKET - 1) code |= 4u; else ps.samples_in_pixel[i] = sip + 1;
+            } else { code |= 2u; nb += 1; }
+            ps.path_throughput[i] = make_float4(tp.x, tp.y, tp.z, 0.0f);
+            ps.num_bounces[i] = nb;
+            ps.flags[i] = 0u;
+            if (finished) {                                                      // logic.js:145-150
+                float4 acc = ps.ticket_acc[i];
+                acc.x += contrib.x; acc.y += contrib.y; acc.z += contrib.z; acc.w += 1.0f;
+                if (code & 4u) {                                                 // ticket complete: flush to the image
+                    float* px = image + 4 * (int64_t)ps.pixel_index[i];
+                    unsafeAtomicAdd(px + 0, acc.x); unsafeAtomicAdd(px + 1, acc.y);
+                    unsafeAtomicAdd(px + 2, acc.z); unsafeAtomicAdd(px + 3, acc.w);
+                    acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+                ps.ticket_acc[i] = acc;
+            }
+        }
     }
+    if (i < rc.num_paths) code_out[i] = (uint8_t)code;
+    unsigned long long b_cam = __ballot(code & 1u), b_mat = __ballot(code & 2u), b_tix = __ballot(code & 4u), b_fin = __ballot(finished);
+    if (lane_id() == 0)
+        s_wave[threadIdx.x >> 6] = make_int4(__popcll(b_cam), __popcll(b_mat), __popcll(b_tix), __popcll(b_fin));
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int4 t = s_wave[0];
+        for (int w = 1; w < PT_STEP_BLOCK / 64; w++) t = add4(t, s_wave[w]);
+        blk_counts[blockIdx.x] = t;
+    }
+}
+
+// ============================================================================================
+// compact + generate + shade: stable scatter into the camera / material queues and pixel tickets (logic.js:155-219),
+// then the slot's next ray by the same thread -- the camera ray of a slot that starts a sample (camera.js:60-118) or
+// the bounce ray of a slot that continues (material.js:75-120); both only touch that slot's own state, so neither
+// waits for a queue.  Workgroup 0 also closes the step's books in the StepHeader.
+// No scan launch: logic leaves one count record per 1024 slots (~1000 per step); a workgroup here (256 slots) adds up
+// the records in front of its 1024-slot group (<= 4 16-B loads per thread, L2 resident) and re-counts the codes of the
+// <= 3 workgroups in front of it inside the group.  Measured alternatives: a one-workgroup scan launch (9 us of
+// pure latency per step), "last logic workgroup to arrive scans" (+100 us of contended arrivals), per-64-workgroup
+// totals kept with integer atomics in logic (+25 us: 4 atomics per workgroup, profiles/r01_step_fusion_*).
+// ============================================================================================
+__device__ __forceinline__ int4 wave_sum4(int4 v) {
+    for (int off = 32; off > 0; off >>= 1)
+        v = add4(v, make_int4(__shfl_xor(v.x, off), __shfl_xor(v.y, off), __shfl_xor(v.z, off), __shfl_xor(v.w, off)));
+    return v;
+}
+__global__ __launch_bounds__(PT_BLOCK) void k_compact_generate_shade(PathState ps, RenderConst rc, SceneView sc, const uint8_t* __restrict__ code_in,
+                                                                     const int4* __restrict__ blk_counts, int nrecords, int parity, StepHeader* hdr,
+                                                                     int32_t* __restrict__ cam_q, int32_t* __restrict__ mat_q) {
+    constexpr int NW = PT_BLOCK / 64, PER = PT_STEP_BLOCK / PT_BLOCK;
+    __shared__ int4 s_wave[NW], s_front[NW], s_all[NW];
+    const int b = blockIdx.x, group = b / PER, sub = b % PER, wave = threadIdx.x >> 6, lane = lane_id();
+    int i = b * PT_BLOCK + threadIdx.x;
+    unsigned code = i < rc.num_paths ? code_in[i] : 0u;
+    unsigned long long b_cam = __ballot(code & 1u), b_mat = __ballot(code & 2u), b_tix = __ballot(code & 4u);
+    if (lane == 0) s_wave[wave] = make_int4(__popcll(b_cam), __popcll(b_mat), __popcll(b_tix), 0);
+    const int64_t ticket_base = hdr->ticket_next[parity];
+    {   // counts in front of this workgroup; workgroup 0 adds up all records for the header
+        const int upto = b == 0 ? nrecords : group;
+        int4 acc = make_int4(0, 0, 0, 0);
+        for (int j = threadIdx.x; j < upto; j += PT_BLOCK) acc = add4(acc, blk_counts[j]);
+        for (int k = 0; k < sub; k++) {
+            unsigned c = code_in[(group * PER + k) * PT_BLOCK + threadIdx.x];
+            acc.x += c & 1u; acc.y += (c >> 1) & 1u; acc.z += (c >> 2) & 1u;
+        }
+        acc = wave_sum4(acc);
+        if (lane == 0) { if (b == 0) s_all[wave] = acc; s_front[wave] = b == 0 ? make_int4(0, 0, 0, 0) : acc; }
+    }
+    __syncthreads();
+    if (b == 0 && wave == NW - 1) {                             // the step's totals -> StepHeader
+        int4 t = make_int4(0, 0, 0, 0);
+        for (int w = 0; w < NW; w++) t = add4(t, s_all[w]);
+        unsigned* cell = &hdr->cls_max[lane >> 1][lane & 1];    // dispatch order of this step's extend launch (StepHeader::cls_max)
+        unsigned v = *cell;
+        *cell = 0;
+        for (int off = 2; off < 64; off <<= 1) v = max(v, (unsigned)__shfl_xor((int)v, off));
+        unsigned cam = __shfl((int)v, 0), mat = __shfl((int)v, 1);
+        if (lane == 0) {
+            hdr->extend_order = mat > cam ? 1 : 0;
+            hdr->n_camera = t.x; hdr->n_material = t.y; hdr->n_rays = t.x + t.y;
+            hdr->ticket_base = ticket_base;
+            hdr->pixel_counter = ticket_base + t.z;
+            hdr->ticket_next[parity ^ 1] = ticket_base + t.z;
+            hdr->total_rays += (int64_t)t.x + t.y;
+            hdr->total_samples += t.w;
+            if (t.x + t.y == 0 && hdr->first_empty_step < 0) hdr->first_empty_step = hdr->step_index;
+            hdr->step_index += 1;
+            hdr->work_counter = 0;
+        }
+    }
+    int4 off = make_int4(0, 0, 0, 0);
+    for (int w = 0; w < NW; w++) { off = add4(off, s_front[w]); if (w < wave) off = add4(off, s_wave[w]); }
+    if (code & 1u) cam_q[off.x + rank_below(b_cam)] = i;
+    if (code & 2u) mat_q[off.y + rank_below(b_mat)] = i;
+    if (code & 4u) {
+        int64_t ticket = ticket_base + off.z + rank_below(b_tix);
+        if (ticket >= rc.ticket_limit) ps.flags[i] |= (1u << 31);                  // logic.js:177-179
+        else {                                                                      // logic.js:181-182
+            ps.pixel_index[i] = (int32_t)(ticket % ((int64_t)rc.width * rc.height));
+            ps.samples_in_pixel[i] = 0;
+        }
+    }
+    if (code & 1u) generate_one(ps, rc, i);
+    if (code & 2u) shade_one(ps, sc, i);
 }
 
 // Adds the unfinished tickets' partial sums to the image (and clears them) so that a host looking at the image in
@@ -283,20 +272,14 @@ __global__ __launch_bounds__(PT_BLOCK) void k_tonemap(const float4* __restrict__
 }
 
 // ---- launchers -------------------------------------------------------------------------------
-void ptk_logic(const PathState& ps, const RenderConst& rc, int first_sample, float* image, uint8_t* code, int4* blk_counts,
-               int4* blk_offsets, StepHeader* hdr, hipStream_t s) {
-    int nblocks = (rc.num_paths + PT_BLOCK - 1) / PT_BLOCK;
-    hipLaunchKernelGGL(k_logic, dim3(nblocks), dim3(PT_BLOCK), 0, s, ps, rc, first_sample, image, code, blk_counts);
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(PT_BLOCK), 0, s, blk_counts, blk_offsets, nblocks, hdr);
+int ptk_step_blocks(int num_paths) { return (num_paths + PT_STEP_BLOCK - 1) / PT_STEP_BLOCK; }
+void ptk_logic(const PathState& ps, const RenderConst& rc, int first_sample, float* image, uint8_t* code, int4* blk_counts, hipStream_t s) {
+    hipLaunchKernelGGL(k_logic, dim3(ptk_step_blocks(rc.num_paths)), dim3(PT_STEP_BLOCK), 0, s, ps, rc, first_sample, image, code, blk_counts);
 }
-void ptk_compact(const PathState& ps, const RenderConst& rc, const uint8_t* code, const int4* blk_offsets, const StepHeader* hdr,
-                 int32_t* cam_q, int32_t* mat_q, hipStream_t s) {
-    hipLaunchKernelGGL(k_compact, grid_for(rc.num_paths), dim3(PT_BLOCK), 0, s, ps, rc, code, blk_offsets, hdr, cam_q, mat_q);
-}
-void ptk_generate_shade(const PathState& ps, const RenderConst& rc, const SceneView& sc, const StepHeader* hdr, const int32_t* cam_q,
-                        const int32_t* mat_q, hipStream_t s) {
-    dim3 grid((unsigned)((rc.num_paths + PT_BLOCK - 1) / PT_BLOCK + 1));   // ceil(c/256) + ceil(m/256) <= this whenever c + m <= num_paths
-    hipLaunchKernelGGL(k_generate_shade, grid, dim3(PT_BLOCK), 0, s, ps, rc, sc, hdr, cam_q, mat_q);
+void ptk_compact_generate_shade(const PathState& ps, const RenderConst& rc, const SceneView& sc, const uint8_t* code, const int4* blk_counts,
+                                int parity, StepHeader* hdr, int32_t* cam_q, int32_t* mat_q, hipStream_t s) {
+    hipLaunchKernelGGL(k_compact_generate_shade, grid_for(rc.num_paths), dim3(PT_BLOCK), 0, s, ps, rc, sc, code, blk_counts,
+                       ptk_step_blocks(rc.num_paths), parity, hdr, cam_q, mat_q);
 }
 void ptk_flush_tickets(const PathState& ps, int num_paths, float* image, hipStream_t s) {
     hipLaunchKernelGGL(k_flush_tickets, grid_for(num_paths), dim3(PT_BLOCK), 0, s, ps, num_paths, image);
