@@ -518,7 +518,7 @@ void orc_brute_force(const orc_scene* s, const float* o3, const float* d3, int64
 #define ALBEDO1_POW 0.0289911870530680f /* pow(0.2, 2.2) material.js:110,72 */
 
 struct orc_render {
-    const orc_scene* scene; orc_render_params p; int64_t num_steps;
+    const orc_scene* scene; orc_render_params p; int64_t num_steps, num_logic, n_live;
     int64_t pixel_counter, ticket_limit;
     int32_t *pixel_index, *num_bounces, *hit_obj, *hit_tri, *samples_in_pixel; uint32_t* flags;
     float *random_seed, *path_throughput, *material_throughput_pdf, *path_o, *path_d;
@@ -659,21 +659,28 @@ static void material_slot(orc_render* r, int32_t path) {
     po[0] = no.x; po[1] = no.y; po[2] = no.z; pd[0] = nd.x; pd[1] = nd.y; pd[2] = nd.z;
 }
 
-void orc_render_step(orc_render* r, orc_step_stats* out, int threads) {
-    int64_t n = r->p.num_paths; int first = r->num_steps == 0;
-    if (threads < 1) threads = 1;
-    /* logic.js (state machine part) */
+/* One step() of the reference is four dispatches: logic, camera, material, ray-trace (path-tracer.js:49-123).  They are
+ * kept as separately callable phases because the camera and the material phase touch disjoint slots (code bit 0 / bit 1)
+ * and therefore commute: an implementation may run "material" right behind "logic" for the same slot and hand out
+ * tickets / camera rays afterwards.  orc_render_step runs them in the reference's order. */
+static void phase_logic(orc_render* r, int threads) {           /* logic.js:62-152 + image adds :145-150,222-233 */
+    int64_t n = r->p.num_paths; int first = r->num_logic == 0;
 #pragma omp parallel for schedule(static) num_threads(threads)
     for (int64_t i = 0; i < n; i++) logic_slot(r, i, first);
-    /* canonical serial order: image adds (:145-150), pixel tickets (:155-184), queue appends (:187-219) */
-    int64_t npix = (int64_t)r->p.width * r->p.height, n_live = 0;
-    r->n_camera = r->n_material = 0;
-    for (int64_t i = 0; i < n; i++) {
-        const float* c = r->contrib + 4 * i; uint8_t code = r->code[i];
+    for (int64_t i = 0; i < n; i++) {                           /* canonical serial order of the adds */
+        const float* c = r->contrib + 4 * i;
         if (c[0] != 0.0f || c[1] != 0.0f || c[2] != 0.0f || c[3] != 0.0f) {
             float* px = r->image + 4 * (int64_t)r->pixel_index[i];
             px[0] += c[0]; px[1] += c[1]; px[2] += c[2]; px[3] += c[3];
         }
+    }
+    r->num_logic++;
+}
+static void phase_queues_camera(orc_render* r, int threads) {   /* logic.js:155-219 (tickets, queues), camera.js */
+    int64_t n = r->p.num_paths, npix = (int64_t)r->p.width * r->p.height, n_live = 0;
+    r->n_camera = r->n_material = 0;
+    for (int64_t i = 0; i < n; i++) {                           /* canonical serial order: ascending slot */
+        uint8_t code = r->code[i];
         if (code & 4) {
             int64_t ticket = r->pixel_counter++;
             if (ticket >= r->ticket_limit) r->flags[i] |= (1u << 31);
@@ -683,12 +690,16 @@ void orc_render_step(orc_render* r, orc_step_stats* out, int threads) {
         if (code & 2) r->material_queue[r->n_material++] = (int32_t)i;
         if (!(r->flags[i] & (1u << 31))) n_live++;
     }
-    /* camera.js, material.js */
+    r->n_live = n_live;
 #pragma omp parallel for schedule(static) num_threads(threads)
     for (int64_t q = 0; q < r->n_camera; q++) camera_slot(r, r->camera_queue[q]);
+}
+static void phase_material(orc_render* r, int threads) {        /* material.js over the slots logic sent on (code bit 1) */
+    int64_t n = r->p.num_paths;
 #pragma omp parallel for schedule(static) num_threads(threads)
-    for (int64_t q = 0; q < r->n_material; q++) material_slot(r, r->material_queue[q]);
-    /* ray-trace.js:53-69 over camera ++ material */
+    for (int64_t i = 0; i < n; i++) if (r->code[i] & 2) material_slot(r, (int32_t)i);
+}
+static void phase_trace(orc_render* r, int threads) {           /* ray-trace.js:53-69 over camera ++ material */
     int64_t n_rays = r->n_camera + r->n_material, bytes = 0;
 #pragma omp parallel for schedule(dynamic, 256) num_threads(threads) reduction(+ : bytes)
     for (int64_t q = 0; q < n_rays; q++) {
@@ -698,7 +709,20 @@ void orc_render_step(orc_render* r, orc_step_stats* out, int threads) {
         bytes += 44 + 64 * (int64_t)h.n_inner + 48 * (int64_t)h.n_leaf + 128 * (int64_t)(h.n_enter + h.n_leave);
     }
     r->total_rays += n_rays; r->traversal_bytes += bytes; r->num_steps++;
-    if (out) { out->n_camera = r->n_camera; out->n_material = r->n_material; out->n_rays = n_rays; out->n_live = n_live; }
+}
+void orc_render_phase(orc_render* r, int phase, orc_step_stats* out, int threads) {
+    if (threads < 1) threads = 1;
+    if (phase == ORC_PHASE_LOGIC) phase_logic(r, threads);
+    else if (phase == ORC_PHASE_QUEUES_CAMERA) phase_queues_camera(r, threads);
+    else if (phase == ORC_PHASE_MATERIAL) phase_material(r, threads);
+    else if (phase == ORC_PHASE_TRACE) phase_trace(r, threads);
+    if (out) { out->n_camera = r->n_camera; out->n_material = r->n_material; out->n_rays = r->n_camera + r->n_material; out->n_live = r->n_live; }
+}
+void orc_render_step(orc_render* r, orc_step_stats* out, int threads) {
+    orc_render_phase(r, ORC_PHASE_LOGIC, NULL, threads);
+    orc_render_phase(r, ORC_PHASE_QUEUES_CAMERA, NULL, threads);
+    orc_render_phase(r, ORC_PHASE_MATERIAL, NULL, threads);
+    orc_render_phase(r, ORC_PHASE_TRACE, out, threads);
 }
 
 int64_t orc_render_run(orc_render* r, int64_t max_steps, int64_t* total_rays, int64_t* traversal_bytes, int threads) {

@@ -102,6 +102,10 @@ typedef struct orc_render orc_render;
 orc_render* orc_render_create(const orc_scene*, const orc_render_params*);
 void        orc_render_destroy(orc_render*);
 void        orc_render_step(orc_render*, orc_step_stats* out, int threads);
+/* the four dispatches of a step, one at a time (step = LOGIC, QUEUES_CAMERA, MATERIAL, TRACE; QUEUES_CAMERA and MATERIAL
+ * touch disjoint slots and may be swapped) */
+enum { ORC_PHASE_LOGIC = 0, ORC_PHASE_QUEUES_CAMERA = 1, ORC_PHASE_MATERIAL = 2, ORC_PHASE_TRACE = 3 };
+void        orc_render_phase(orc_render*, int phase, orc_step_stats* out, int threads);
 /* run until both stage-2 queues are empty; returns number of steps */
 int64_t     orc_render_run(orc_render*, int64_t max_steps, int64_t* total_rays, int64_t* traversal_bytes, int threads);
 const float*    orc_render_image(const orc_render*);             /* W*H*4 */

@@ -132,10 +132,10 @@ int read_back(pt_ctx* c, void* dst, const void* src, size_t bytes) {
 void enqueue_step(pt_ctx* c, int count_visits, hipEvent_t ev0, hipEvent_t ev1) {
     SceneView sv = scene_view(c);
     int parity = (int)(c->step & 1);
-    ptk_logic(c->ps, c->rc, c->step == 0 ? 1 : 0, c->d_image, c->d_code, c->d_blk_counts, c->stream);
-    ptk_compact_generate_shade(c->ps, c->rc, sv, c->d_code, c->d_blk_counts, parity, c->d_hdr, c->d_cam_q, c->d_mat_q, c->stream);
+    if (c->step == 0) ptk_first_logic(c->ps, c->rc, c->d_code, c->stream);
+    ptk_count_compact_generate_shade(c->ps, c->rc, sv, c->d_code, c->d_blk_counts, parity, c->d_hdr, c->d_cam_q, c->d_mat_q, c->stream);
     if (ev0) (void)hipEventRecord(ev0, c->stream);
-    ptk_extend_queue(c->ps, c->rc, sv, c->d_hdr, c->d_cam_q, c->d_mat_q, c->d_spill, count_visits, c->extend_variant, nullptr, c->stream);
+    ptk_extend_queue(c->ps, c->rc, sv, c->d_hdr, c->d_cam_q, c->d_mat_q, c->d_spill, count_visits, c->extend_variant, nullptr, c->d_image, c->d_code, c->stream);
     if (ev1) (void)hipEventRecord(ev1, c->stream);
     c->step++;
 }
@@ -365,7 +365,7 @@ int pt_render_init(pt_ctx* c, const pt_render_params* p) {
         (r = ralloc(c, &ps.samples_in_pixel, n)) || (r = ralloc(c, &ps.ticket_acc, n)))
         return r;
     c->nblocks = ptk_step_blocks((int)np);
-    if ((r = ralloc(c, &c->d_code, n)) || (r = ralloc(c, &c->d_blk_counts, (size_t)c->nblocks)) ||
+    if ((r = ralloc(c, &c->d_code, (size_t)c->nblocks * PT_STEP_BLOCK)) || (r = ralloc(c, &c->d_blk_counts, (size_t)c->nblocks)) ||
         (r = ralloc(c, &c->d_cam_q, n)) || (r = ralloc(c, &c->d_mat_q, n)) || (r = ralloc(c, &c->d_spill, ptk_spill_ints(np))) ||
         (r = ralloc(c, &c->d_hdr, 1)))
         return r;
@@ -507,7 +507,7 @@ int pt_extend_replay(pt_ctx* c, int variant, int reps, double* avg_us) {
     for (int i = 0; i < reps; i++) {   // the kernel only reads path_o/path_d and rewrites the same hit_obj/hit_tri: idempotent
         HIPOK(c, hipMemsetAsync(&c->d_hdr->work_counter, 0, 4, c->stream));
         HIPOK(c, hipEventRecord(e0, c->stream));
-        ptk_extend_queue(c->ps, c->rc, sv, c->d_hdr, c->d_cam_q, c->d_mat_q, c->d_spill, 0, variant, nullptr, c->stream);
+        ptk_extend_queue(c->ps, c->rc, sv, c->d_hdr, c->d_cam_q, c->d_mat_q, c->d_spill, 0, variant, nullptr, nullptr, nullptr, c->stream);
         HIPOK(c, hipEventRecord(e1, c->stream));
         HIPOK(c, hipEventSynchronize(e1));
         float ms = 0; HIPOK(c, hipEventElapsedTime(&ms, e0, e1)); total_ms += ms;
@@ -527,7 +527,7 @@ int pt_extend_wave_log(pt_ctx* c, int variant, uint64_t* out, int64_t cap_waves,
     unsigned long long* d_log = nullptr; int r;
     if ((r = dalloc(c, &d_log, (size_t)n * 4, true))) return r;
     SceneView sv = scene_view(c);
-    ptk_extend_queue(c->ps, c->rc, sv, c->d_hdr, c->d_cam_q, c->d_mat_q, c->d_spill, 0, variant, d_log, c->stream);
+    ptk_extend_queue(c->ps, c->rc, sv, c->d_hdr, c->d_cam_q, c->d_mat_q, c->d_spill, 0, variant, d_log, nullptr, nullptr, c->stream);
     HIPOK(c, hipGetLastError());
     r = read_back(c, out, d_log, (size_t)n * 32);
     dfree(d_log);

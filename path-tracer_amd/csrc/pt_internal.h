@@ -79,15 +79,17 @@ hipError_t pt_sort_pairs_u32(void* tmp, size_t* tmp_bytes, const uint32_t* kin, 
                              const int32_t* vin, int32_t* vout, size_t n, hipStream_t s);
 
 // ---- launchers (pt_kernels_render.hip) --------------------------------------------------------
-int  ptk_step_blocks(int num_paths);   // workgroups (= count records) of the two step kernels below
-void ptk_logic(const PathState& ps, const RenderConst& rc, int first_sample, float* image, uint8_t* code, int4* blk_counts, hipStream_t s);
-// parity = step & 1 (StepHeader::ticket_next)
-void ptk_compact_generate_shade(const PathState& ps, const RenderConst& rc, const SceneView& sc, const uint8_t* code, const int4* blk_counts,
-                                int parity, StepHeader* hdr, int32_t* cam_q, int32_t* mat_q, hipStream_t s);
-// Extend over the step's ray queue (camera ++ material).  count != 0 selects the visit-counting variant.
+int  ptk_step_blocks(int num_paths);   // count records per step; the code array holds PT_STEP_BLOCK bytes per record, zero padded
+void ptk_first_logic(const PathState& ps, const RenderConst& rc, uint8_t* code, hipStream_t s);   // before step 0 only
+// counts -> queues, tickets, camera rays, StepHeader.  parity = step & 1 (StepHeader::ticket_next)
+void ptk_count_compact_generate_shade(const PathState& ps, const RenderConst& rc, const SceneView& sc, const uint8_t* code, int4* blk_counts, int parity, StepHeader* hdr,
+                                int32_t* cam_q, int32_t* mat_q, hipStream_t s);
+// Extend over the step's ray queue (camera ++ material), followed per slot by the next step's logic and material sample
+// (code != null; they write the decision codes the next ptk_count_compact_generate reads).  code == null: traversal only.
+// count != 0 selects the visit-counting variant.
 void ptk_extend_queue(const PathState& ps, const RenderConst& rc, const SceneView& sc, StepHeader* hdr,
                       const int32_t* cam_q, const int32_t* mat_q, int32_t* spill, int count, int variant,
-                      unsigned long long* wave_log /* null unless measuring */, hipStream_t s);
+                      unsigned long long* wave_log /* null unless measuring */, float* image, uint8_t* code, hipStream_t s);
 int64_t ptk_extend_waves(int num_paths, int variant);   // waves the launch of that variant holds (wave_log entries)
 int ptk_extend_num_variants();
 const char* ptk_extend_variant_name(int v);

@@ -9,8 +9,7 @@
 // Stack: the first LDS_N entries of a lane's stack live in LDS as [entry][thread] (bank = thread & 31
 // whatever the entry, lanes l / l+32 are served in different LDS cycles: divergent depths never
 // conflict); deeper entries go to an HBM spill laid out [entry][slot] so that equal depths coalesce.
-#include "pt_internal.h"
-#include "pt_math.cuh"
+#include "pt_shading.cuh"
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int rank_below(unsigned long long mask) {
@@ -156,10 +155,14 @@ __device__ __forceinline__ void publish(unsigned long long ov, unsigned long lon
 // --------------------------------------------------------------------------------------------
 // LOG (measurement only, tools/wave_timeline.py): every wave records {start, end} in 100 MHz ticks, where it ran and how
 // many trips it took -- wave_log[4 * wave] = {t0, t1, XCC_ID << 32 | HW_ID, block << 32 | class << 24 | trips}.
-template <int LDS_N, int BLOCK, bool COUNT, int ORDER, bool LOG>
+// LOGIC: the thread that traced a slot's ray goes straight on with that slot's logic (logic.js:62-152): it touches only
+// the slot's own state, the hit is still in registers, and its memory traffic hides under the traversal of the other
+// waves instead of costing a launch.  (The material sample too was tried here: its ~90 registers take the traversal from
+// 8 to 5 waves per SIMD, +30 us per launch; capped at 64 registers it spills, +43 us.  It runs in the compaction launch.)
+template <int LDS_N, int BLOCK, bool COUNT, int ORDER, bool LOG, bool LOGIC>
 __global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView sc, StepHeader* hdr, const int32_t* __restrict__ cam_q,
                                                         const int32_t* __restrict__ mat_q, int32_t* spill, int64_t spill_stride,
-                                                        unsigned long long* wave_log) {
+                                                        unsigned long long* wave_log, float* __restrict__ image, uint8_t* __restrict__ code_out) {
     unsigned long long t_start = LOG ? wall_clock64() : 0;
     __shared__ int s_stack[LDS_N * BLOCK];
     int n_cam = hdr->n_camera, n_rays = n_cam + hdr->n_material;
@@ -179,6 +182,10 @@ __global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView 
         while (trav_step<COUNT>(sc, r, stk)) {}
         trav_finish<COUNT>(sc, r);
         ps.hit_obj[path] = r.hit_obj; ps.hit_tri[path] = r.hit_tri;
+        if (LOGIC) {
+            unsigned code = logic_one(ps, image, path, r.hit_obj >= 0);
+            code_out[path] = (uint8_t)code;
+        }
     }
     publish<COUNT>(r.overflow, r.n_inner, r.n_leaf, r.n_enter, r.n_leave, hdr);
     if (LOG) {
@@ -229,12 +236,16 @@ size_t ptk_spill_ints(int64_t n_rays) { return (size_t)pad_to(n_rays, 256) * (PT
 
 template <int LDS_N, int BLOCK, int ORDER>
 static void launch_queue(const PathState& ps, int num_paths, const SceneView& sc, StepHeader* hdr, const int32_t* cam_q,
-                         const int32_t* mat_q, int32_t* spill, int count, unsigned long long* wave_log, hipStream_t s) {
+                         const int32_t* mat_q, int32_t* spill, int count, unsigned long long* wave_log, float* image, uint8_t* code, hipStream_t s) {
     int64_t stride = pad_to(num_paths, 256);
     dim3 grid((unsigned)((num_paths + BLOCK - 1) / BLOCK));
-    if (wave_log)   hipLaunchKernelGGL((k_extend_queue<LDS_N, BLOCK, false, ORDER, true>), grid, dim3(BLOCK), 0, s, ps, sc, hdr, cam_q, mat_q, spill, stride, wave_log);
-    else if (count) hipLaunchKernelGGL((k_extend_queue<LDS_N, BLOCK, true, ORDER, false>), grid, dim3(BLOCK), 0, s, ps, sc, hdr, cam_q, mat_q, spill, stride, wave_log);
-    else            hipLaunchKernelGGL((k_extend_queue<LDS_N, BLOCK, false, ORDER, false>), grid, dim3(BLOCK), 0, s, ps, sc, hdr, cam_q, mat_q, spill, stride, wave_log);
+#define PT_LAUNCH(COUNT, LOG, LOGIC) hipLaunchKernelGGL((k_extend_queue<LDS_N, BLOCK, COUNT, ORDER, LOG, LOGIC>), grid, dim3(BLOCK), 0, s, ps, sc, hdr, \
+                                                       cam_q, mat_q, spill, stride, wave_log, image, code)
+    if (wave_log)    PT_LAUNCH(false, true, false);    // measurement replays (code == null): traversal only, idempotent
+    else if (!code)  PT_LAUNCH(false, false, false);
+    else if (count)  PT_LAUNCH(true, false, true);
+    else             PT_LAUNCH(false, false, true);
+#undef PT_LAUNCH
 }
 
 // Variants differ in workgroup size and in how much of the stack is in LDS (occupancy); results are identical.
@@ -255,10 +266,11 @@ static const char* kVariantNames[] = {"256-thread workgroups, 24 LDS stack entri
 int ptk_extend_num_variants() { return 3; }
 const char* ptk_extend_variant_name(int v) { return (v >= 0 && v < 3) ? kVariantNames[v] : "?"; }
 void ptk_extend_queue(const PathState& ps, const RenderConst& rc, const SceneView& sc, StepHeader* hdr, const int32_t* cam_q,
-                      const int32_t* mat_q, int32_t* spill, int count, int variant, unsigned long long* wave_log, hipStream_t s) {
-    if (variant == 0)      launch_queue<24, 256, 1>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, s);
-    else if (variant == 1) launch_queue<16, 64, 1>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, s);
-    else                   launch_queue<16, 64, 2>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, s);
+                      const int32_t* mat_q, int32_t* spill, int count, int variant, unsigned long long* wave_log, float* image, uint8_t* code,
+                      hipStream_t s) {
+    if (variant == 0)      launch_queue<24, 256, 1>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, s);
+    else if (variant == 1) launch_queue<16, 64, 1>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, s);
+    else                   launch_queue<16, 64, 2>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, s);
 }
 int64_t ptk_extend_waves(int num_paths, int variant) {
     int block = variant == 0 ? 256 : 64;

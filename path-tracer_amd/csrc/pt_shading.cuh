@@ -1,0 +1,145 @@
+// pt_shading.cuh -- the per-slot bodies of the logic, camera and material kernels (logic.js:62-152, camera.js:60-118,
+// material.js:75-120).  Each only reads and writes its own slot's PathState (plus the image), which is what lets the
+// launches in pt_kernels_render.hip / pt_kernels_extend.hip call them from whichever thread holds the slot.
+#pragma once
+#include "pt_internal.h"
+#include "pt_math.cuh"
+
+#define ALBEDO0_POW 0.217637640824031f   // pow(0.5, 2.2): material.js:107 through :72
+#define ALBEDO1_POW 0.0289911870530680f  // pow(0.2, 2.2): material.js:110 through :72
+
+// code bits: 1 = camera queue, 2 = material queue, 4 = wants a pixel ticket, 8 = finished a sample this step
+#define PT_CODE_CAMERA 1u
+#define PT_CODE_MATERIAL 2u
+#define PT_CODE_TICKET 4u
+#define PT_CODE_FINISHED 8u
+
+// ============================================================================================
+// generate (camera.js:60-118)
+// ============================================================================================
+__device__ __forceinline__ void generate_one(const PathState& ps, const RenderConst& rc, int path) {
+    int px = ps.pixel_index[path];
+    float seed = ps.random_seed[path];
+    float2 r2 = rand2(seed);
+    ps.random_seed[path] = seed + 2.0f;
+    float cx = (float)(px % rc.width) + r2.x, cy = (float)(px / rc.width) + r2.y;
+    float sx = cx / (float)rc.width, sy = cy / (float)rc.height;
+    sx = sx * 2.0f - 1.0f; sy = sy * 2.0f - 1.0f; sy *= -1.0f;
+    float aspect = (float)rc.width / (float)rc.height;
+    float sn, cs; pt_sincos(rc.fov_deg * 3.14159265358979323846f / 180.0f, sn, cs);
+    f3 local = F3(aspect * sx * sn, 1.0f, sy * sn);
+    f3 pos = F3(rc.cam_pos[0], rc.cam_pos[1], rc.cam_pos[2]);
+    f3 fwd = normalize3(F3(rc.cam_look_at[0], rc.cam_look_at[1], rc.cam_look_at[2]) - pos);
+    f3 right = normalize3(F3(fwd.y, -fwd.x, 0.0f));
+    f3 up = cross3(right, fwd);
+    f3 w = normalize3(local);
+    f3 d = (right * w.x + fwd * w.y) + up * w.z;
+    ps.path_o[path] = make_float4(pos.x, pos.y, pos.z, 0.0f);
+    ps.path_d[path] = make_float4(d.x, d.y, d.z, 0.0f);
+}
+
+// ============================================================================================
+// shade (material.js:75-120; scene.js:204-258 get_triangle_hit_info)
+// ============================================================================================
+// STAGED: the three groups of loads (world-to-local rows, triangle, local-to-world rows) are issued one after the other
+// instead of all up front, which keeps the live registers under the extend kernel's 64 (8 waves per SIMD); the arithmetic
+// is the same.
+template <bool STAGED = false>
+__device__ __forceinline__ void shade_one(const PathState& ps, const SceneView& sc, int path, int hit_obj, int hit_tri) {
+    f3 o = F3(ps.path_o[path]), d = F3(ps.path_d[path]);
+    const float4* ob = sc.objects + 8 * (int64_t)hit_obj;
+    f3 lo, ld; int mat;
+    {
+        float4 inf = ob[3], w0 = ob[4], w1 = ob[5], w2 = ob[6];
+        lo = xform(w0, w1, w2, o, 1.0f); ld = xform(w0, w1, w2, d, 0.0f);
+        mat = __float_as_int(inf.y);
+    }
+    if (STAGED) asm volatile("" ::: "memory");
+    f3 ln, lhit;
+    {
+        const float4* tr = sc.tris + 3 * (int64_t)hit_tri;
+        f3 v0 = F3(tr[0]), v0v1 = F3(tr[1]) - v0, v0v2 = F3(tr[2]) - v0;
+        f3 pvec = cross3(ld, v0v2);
+        float det = dot3(v0v1, pvec), i_det = 1.0f / det;
+        f3 tvec = lo - v0;
+        f3 qvec = cross3(tvec, v0v1);
+        ln = normalize3(cross3(v0v1, v0v2));
+        float ldist = dot3(v0v2, qvec) * i_det;
+        lhit = lo + ld * ldist;
+    }
+    if (STAGED) asm volatile("" ::: "memory");
+    float4 l0 = ob[0], l1 = ob[1], l2 = ob[2];
+    f3 whit = xform(l0, l1, l2, lhit, 1.0f);
+    f3 n = normalize3(xform(l0, l1, l2, ln, 0.0f));
+    float dist = length3(whit - o);
+    f3 hit_pos = o + d * dist;
+    f3 ov = __builtin_fabsf(n.x) > __builtin_fabsf(n.y) ? F3(-n.y, n.x, 0.0f) : F3(0.0f, -n.z, n.y);   // material.js:166-171
+    f3 o1 = normalize3(ov), o2 = normalize3(cross3(o1, n));
+    float seed = ps.random_seed[path];
+    float4 bp = make_float4(0.0f, 0.0f, 0.0f, 0.0f); f3 wi = F3(0.0f, 0.0f, 0.0f);
+    if (mat == 0 || mat == 1) {                                                  // material.js:106-111
+        float2 r2 = rand2(seed); seed += 2.0f;
+        float rad = __builtin_sqrtf(fmax_(r2.x, 0.0f)), sn, cs;                    // material.js:141-151
+        pt_sincos(6.283185307179586f * r2.y, sn, cs);
+        float dx = rad * cs, dy = rad * sn;
+        float z = __builtin_sqrtf(fmax_(0.0f, (1.0f - dx * dx) - dy * dy));
+        wi = F3(dx, dy, z);
+        float a = mat == 0 ? ALBEDO0_POW : ALBEDO1_POW;
+        bp = make_float4(a, a, a, wi.z);
+    }
+    f3 nd = (o1 * wi.x + o2 * wi.y) + n * wi.z;
+    f3 no = hit_pos + n * 0.0001f;
+    ps.material_throughput_pdf[path] = bp;
+    ps.flags[path] |= 1u;
+    ps.random_seed[path] = seed;
+    ps.path_o[path] = make_float4(no.x, no.y, no.z, 0.0f);
+    ps.path_d[path] = make_float4(nd.x, nd.y, nd.z, 0.0f);
+}
+
+// ============================================================================================
+// logic (logic.js:62-152) for a slot whose ray has been traced: state machine, image accumulation, decision.
+// Image accumulation: a slot owns its pixel for the 8 samples of a ticket (logic.js:6,129), so the samples are
+// summed in the slot's ticket accumulator and reach the image with ONE group of float atomics per ticket instead
+// of one per sample (scattered float atomics are the slowest memory operation on this chip).  The reference's
+// own add order is a race (logic.js:222-233); sample counts stay exact.
+// ============================================================================================
+__device__ __forceinline__ unsigned logic_one(const PathState& ps, float* __restrict__ image, int i, bool b_hit) {
+    unsigned code = 0; bool finished = false;
+    if ((ps.flags[i] & (1u << 31)) != 0u) return 0u;                             // logic.js:66 a slot past the last ticket
+    f3  tp = F3(ps.path_throughput[i]);
+    int nb = ps.num_bounces[i] + 1;
+    uint32_t flags = ps.flags[i];
+    f3 contrib = F3(0.0f, 0.0f, 0.0f);
+    if (flags & 1u) {                                                   // logic.js:94-109
+        tp = tp * F3(ps.material_throughput_pdf[i]);
+        if (nb > 3) {
+            float seed = ps.random_seed[i];
+            float2 r2 = rand2(seed);
+            ps.random_seed[i] = seed + 2.0f;
+            float q = fmin_(fmax_(0.1f, 1.0f - tp.y), 0.7f);
+            if (r2.x < q) tp = F3(0.0f, 0.0f, 0.0f); else tp = tp / (1.0f - q);
+        }
+    }
+    if (nb > 20) tp = F3(0.0f, 0.0f, 0.0f);                              // logic.js:111-113
+    if (!b_hit) { contrib = F3(0.0f + 2.0f * tp.x, 0.0f + 2.0f * tp.y, 0.0f + 2.0f * tp.z); tp = F3(0.0f, 0.0f, 0.0f); }
+    if (tp.x == 0.0f && tp.y == 0.0f && tp.z == 0.0f) {                  // logic.js:121-133
+        finished = true; code |= 1u; nb = 0; tp = F3(1.0f, 1.0f, 1.0f);
+        int sip = ps.samples_in_pixel[i];
+        if (sip >= PT_SAMPLES_PER_TICKET - 1) code |= 4u; else ps.samples_in_pixel[i] = sip + 1;
+    } else { code |= 2u; nb += 1; }
+    ps.path_throughput[i] = make_float4(tp.x, tp.y, tp.z, 0.0f);
+    ps.num_bounces[i] = nb;
+    ps.flags[i] = 0u;
+    if (finished) {                                                      // logic.js:145-150
+        float4 acc = ps.ticket_acc[i];
+        acc.x += contrib.x; acc.y += contrib.y; acc.z += contrib.z; acc.w += 1.0f;
+        if (code & 4u) {                                                 // ticket complete: flush to the image
+            float* px = image + 4 * (int64_t)ps.pixel_index[i];
+            unsafeAtomicAdd(px + 0, acc.x); unsafeAtomicAdd(px + 1, acc.y);
+            unsafeAtomicAdd(px + 2, acc.z); unsafeAtomicAdd(px + 3, acc.w);
+            acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+        ps.ticket_acc[i] = acc;
+    }
+    return code | (finished ? PT_CODE_FINISHED : 0u);
+}

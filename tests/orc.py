@@ -51,6 +51,7 @@ def lib():
             "orc_brute_force": (None, [vp, vp, vp, i64, vp, vp, vp, i32]),
             "orc_render_create": (vp, [vp, C.POINTER(OrcRenderParams)]), "orc_render_destroy": (None, [vp]),
             "orc_render_step": (None, [vp, C.POINTER(OrcStepStats), i32]),
+            "orc_render_phase": (None, [vp, i32, C.POINTER(OrcStepStats), i32]),
             "orc_render_run": (i64, [vp, i64, C.POINTER(i64), C.POINTER(i64), i32]),
             "orc_render_image": (vp, [vp]),
             "orc_render_field": (vp, [vp, C.c_char_p, C.POINTER(C.c_size_t)]),
@@ -169,6 +170,26 @@ class OrcRender:
     def step(self, threads=THREADS):
         st = OrcStepStats()
         lib().orc_render_step(self.h, C.byref(st), threads)
+        return st
+
+    LOGIC, QUEUES_CAMERA, MATERIAL, TRACE = 0, 1, 2, 3
+
+    def phase(self, which, threads=THREADS):
+        st = OrcStepStats()
+        lib().orc_render_phase(self.h, which, C.byref(st), threads)
+        return st
+
+    def step_like_device(self, threads=THREADS):
+        """The reference's dispatches grouped the way the HIP step groups them (DESIGN.md 'step'): the device runs the
+        logic of step k+1 in the tail of step k's extend kernel, so its step k is [tickets+queues+camera rays, material,
+        trace, logic of step k+1], preceded once by the first logic.  Same global sequence as step().  Returns the stats
+        of the traced queues (the trailing logic phase does not touch the queue arrays)."""
+        if not getattr(self, "_primed", False):
+            self.phase(self.LOGIC, threads); self._primed = True
+        self.phase(self.QUEUES_CAMERA, threads)
+        self.phase(self.MATERIAL, threads)
+        st = self.phase(self.TRACE, threads)
+        self.phase(self.LOGIC, threads)
         return st
 
     def run(self, max_steps=1 << 40, threads=THREADS):

@@ -128,7 +128,7 @@ def test_path_state_bit_exact_step_by_step(pta, orc, device, built, name, w, h, 
                                "settings": {"samples": spp, "numPaths": paths}})
     orr = orc.OrcRender(o, w, h, desc["camera"], spp, paths)
     for step in range(30):
-        gs = pt.step(); cs = orr.step()
+        gs = pt.step(); cs = orr.step_like_device()
         assert (gs.n_camera, gs.n_material, gs.n_rays) == (cs.n_camera, cs.n_material, cs.n_rays), step
         np.testing.assert_array_equal(pt.queue(0), orr.queue(0))
         np.testing.assert_array_equal(pt.queue(1), orr.queue(1))
@@ -243,7 +243,7 @@ def test_full_size_10m_triangle_scene(pta, orc, device):
                                "settings": {"samples": spp, "numPaths": paths}})
     orr = orc.OrcRender(o, w, h, desc["camera"], spp, paths)
     for step in range(6):
-        gs = pt.step(); cs = orr.step(threads=16)
+        gs = pt.step(); cs = orr.step_like_device(threads=16)
         assert (gs.n_camera, gs.n_material) == (cs.n_camera, cs.n_material)
         for f in ("hit_obj", "hit_tri", "pixel_index", "num_bounces"):
             np.testing.assert_array_equal(pt.field(f), orr.field(f))
@@ -283,7 +283,7 @@ def test_deep_stack_uses_the_hbm_spill(pta, orc, device):
     pt = pta.init_path_tracer({"device": device, "scene": s, "image": {"width": 16, "height": 16}, "camera": cam, "settings": {"samples": 8, "numPaths": 256}})
     orr = orc.OrcRender(o, 16, 16, cam, 8, 256)
     for _ in range(2):
-        gs = pt.step(); cs = orr.step(threads=16)
+        gs = pt.step(); cs = orr.step_like_device(threads=16)
         assert gs.n_rays == cs.n_rays
         np.testing.assert_array_equal(pt.field("hit_tri"), orr.field("hit_tri"))
     rs = pt.run(max_steps=2, count_bytes=True)

@@ -252,3 +252,29 @@ def test_ticket_exhaustion_kills_slots(orc, pta):
     assert (r.field("flags") >> 31).sum() == 36
     r.run()
     assert r.image()[..., 3].sum() == 8 * 8 * 8
+
+
+def test_device_phase_order_is_the_reference_order(orc):
+    """The HIP step runs the next step's logic right behind the trace.  The oracle can be stepped either way; both must
+    trace identical queues every step and end in the same state and image, which is what lets the GPU parity tests compare
+    at the device's step boundary."""
+    pta = orc.pta
+    desc = pta.scenes.cornell_box()
+    s = orc.OrcScene(desc)
+    a = orc.OrcRender(s, 48, 27, desc["camera"], 16, 1500)
+    b = orc.OrcRender(s, 48, 27, desc["camera"], 16, 1500)
+    for step in range(40):
+        sa = a.step(); sb = b.step_like_device()
+        assert (sa.n_camera, sa.n_material) == (sb.n_camera, sb.n_material)
+        for q in (0, 1):
+            np.testing.assert_array_equal(a.queue(q), b.queue(q))
+        for f in ("hit_obj", "hit_tri", "pixel_index"):
+            np.testing.assert_array_equal(a.field(f), b.field(f))
+    ra = a.run(); rb_steps = 0
+    while True:
+        st = b.step_like_device(); rb_steps += 1
+        if st.n_rays == 0:
+            break
+    np.testing.assert_array_equal(a.image().view(np.uint32), b.image().view(np.uint32))
+    for f in orc.FIELDS:
+        np.testing.assert_array_equal(a.field(f).view(np.uint32), b.field(f).view(np.uint32))
