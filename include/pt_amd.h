@@ -120,8 +120,8 @@ typedef struct {
     int64_t total_rays;         /* sum of stage-3 queue sizes */
     int64_t total_samples;      /* finished camera samples (= sum of image .w) */
     int64_t stack_overflows;    /* rays that hit the traversal guards (0 on sane scenes) */
-    double  extend_ms;          /* sum of extend-kernel durations (HIP events), if timed */
-    int64_t extend_launches;
+    double  extend_ms;          /* sum of the durations (HIP events) of the timed extend launches: one launch in eight */
+    int64_t extend_launches;    /* how many launches were timed */
     int64_t traversal_bytes;    /* algorithmic bytes if counted, else 0 */
 } pt_run_stats;
 enum { PT_RUN_TIME_EXTEND = 1, PT_RUN_COUNT_BYTES = 2 };
