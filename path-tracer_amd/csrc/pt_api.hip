@@ -373,6 +373,15 @@ int pt_render_init(pt_ctx* c, const pt_render_params* p) {
     if (p->image_dev) { c->d_image = (float*)p->image_dev; c->own_image = false; HIPOK(c, hipMemsetAsync(c->d_image, 0, img_floats * 4, c->stream)); }
     else { if ((r = ralloc(c, &c->d_image, img_floats))) return r; c->own_image = true; }
     HIPOK(c, hipHostMalloc((void**)&c->h_hdr, sizeof(StepHeader), hipHostMallocDefault));
+    {   // the pixel-independent part of the camera: evaluated by the device (same arithmetic as every other kernel), kept in rc
+        CameraFrame* d_cf = nullptr;
+        if ((r = dalloc(c, &d_cf, 1, true))) return r;
+        ptk_camera_frame(rc, d_cf, c->stream);
+        HIPOK(c, hipGetLastError());
+        r = read_back(c, &rc.frame, d_cf, sizeof(CameraFrame));
+        dfree(d_cf);
+        if (r) return r;
+    }
     c->render_ready = true;
     return write_header(c);
 }

@@ -59,10 +59,12 @@ struct StepHeader {
     int32_t  extend_order, pad2;         // 0 = camera rays first (queue order), 1 = bounce rays first
 };
 
+struct CameraFrame { float fwd[3], right[3], up[3], fov_sin, aspect; };   // camera.js:96-111, evaluated once per render on the device
 struct RenderConst {
     int32_t width, height, num_paths, spp;
     float   cam_pos[3], cam_look_at[3], fov_deg;
     int64_t slot_base, ticket_limit;
+    CameraFrame frame;
 };
 
 // ---- launchers (pt_kernels_build.hip) ---------------------------------------------------------
@@ -96,6 +98,7 @@ const char* ptk_extend_variant_name(int v);
 // Extend over n caller rays (o4/d4: float4 per ray).  counts4 (int4 per ray) may be null.
 void ptk_extend_direct(const SceneView& sc, const float4* o4, const float4* d4, int n, int32_t* hit_obj,
                        int32_t* hit_tri, float* hit_dist, int4* counts4, int32_t* spill, StepHeader* hdr, hipStream_t s);
+void ptk_camera_frame(const RenderConst& rc, CameraFrame* out_dev, hipStream_t s);   // one thread; the host copies the result into rc.frame
 void ptk_flush_tickets(const PathState& ps, int num_paths, float* image, hipStream_t s);
 void ptk_tonemap(const float4* image, int64_t n_pixels, uint32_t* rgba8, hipStream_t s);
 size_t ptk_spill_ints(int64_t n_rays);   // ints needed in the spill buffer for a launch over n_rays

@@ -162,6 +162,8 @@ __global__ __launch_bounds__(PT_BLOCK) void k_tonemap(const float4* __restrict__
 }
 
 // ---- launchers -------------------------------------------------------------------------------
+__global__ void k_camera_frame(RenderConst rc, CameraFrame* out) { *out = camera_frame(rc); }
+void ptk_camera_frame(const RenderConst& rc, CameraFrame* out_dev, hipStream_t s) { hipLaunchKernelGGL(k_camera_frame, dim3(1), dim3(1), 0, s, rc, out_dev); }
 int ptk_step_blocks(int num_paths) { return (num_paths + PT_STEP_BLOCK - 1) / PT_STEP_BLOCK; }
 void ptk_first_logic(const PathState& ps, const RenderConst& rc, uint8_t* code, hipStream_t s) {
     hipLaunchKernelGGL(k_first_logic, grid_for(rc.num_paths), dim3(PT_BLOCK), 0, s, ps, rc, code);

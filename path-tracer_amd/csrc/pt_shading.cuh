@@ -25,17 +25,32 @@ __device__ __forceinline__ void generate_one(const PathState& ps, const RenderCo
     float cx = (float)(px % rc.width) + r2.x, cy = (float)(px / rc.width) + r2.y;
     float sx = cx / (float)rc.width, sy = cy / (float)rc.height;
     sx = sx * 2.0f - 1.0f; sy = sy * 2.0f - 1.0f; sy *= -1.0f;
-    float aspect = (float)rc.width / (float)rc.height;
-    float sn, cs; pt_sincos(rc.fov_deg * 3.14159265358979323846f / 180.0f, sn, cs);
+    // the camera frame is the same for every slot: camera_frame() below evaluates it once per render (same expressions)
+    const CameraFrame& cf = rc.frame;
+    float aspect = cf.aspect, sn = cf.fov_sin;
     f3 local = F3(aspect * sx * sn, 1.0f, sy * sn);
     f3 pos = F3(rc.cam_pos[0], rc.cam_pos[1], rc.cam_pos[2]);
-    f3 fwd = normalize3(F3(rc.cam_look_at[0], rc.cam_look_at[1], rc.cam_look_at[2]) - pos);
-    f3 right = normalize3(F3(fwd.y, -fwd.x, 0.0f));
-    f3 up = cross3(right, fwd);
+    f3 fwd = F3(cf.fwd[0], cf.fwd[1], cf.fwd[2]), right = F3(cf.right[0], cf.right[1], cf.right[2]), up = F3(cf.up[0], cf.up[1], cf.up[2]);
     f3 w = normalize3(local);
     f3 d = (right * w.x + fwd * w.y) + up * w.z;
     ps.path_o[path] = make_float4(pos.x, pos.y, pos.z, 0.0f);
     ps.path_d[path] = make_float4(d.x, d.y, d.z, 0.0f);
+}
+
+// camera.js:96-111, the part that does not depend on the pixel
+__device__ __forceinline__ CameraFrame camera_frame(const RenderConst& rc) {
+    CameraFrame cf;
+    cf.aspect = (float)rc.width / (float)rc.height;
+    float sn, cs; pt_sincos(rc.fov_deg * 3.14159265358979323846f / 180.0f, sn, cs);
+    cf.fov_sin = sn;
+    f3 pos = F3(rc.cam_pos[0], rc.cam_pos[1], rc.cam_pos[2]);
+    f3 fwd = normalize3(F3(rc.cam_look_at[0], rc.cam_look_at[1], rc.cam_look_at[2]) - pos);
+    f3 right = normalize3(F3(fwd.y, -fwd.x, 0.0f));
+    f3 up = cross3(right, fwd);
+    cf.fwd[0] = fwd.x; cf.fwd[1] = fwd.y; cf.fwd[2] = fwd.z;
+    cf.right[0] = right.x; cf.right[1] = right.y; cf.right[2] = right.z;
+    cf.up[0] = up.x; cf.up[1] = up.y; cf.up[2] = up.z;
+    return cf;
 }
 
 // ============================================================================================
