@@ -63,7 +63,8 @@ __global__ __launch_bounds__(PT_BLOCK) void k_count(const uint32_t* __restrict__
 // pure latency per step), "last logic workgroup to arrive scans" (+100 us of contended arrivals), per-64-workgroup
 // totals kept with integer atomics in logic (+25 us: 4 atomics per workgroup, profiles/r01_step_fusion_*).
 // Also measured: shading here instead of in the extend tail, with logic as its own launch (20.8 + 28.9 us per step
-// against 3 + ~12 us now, profiles/r01_cornell_1080p_64spp_kernel_stats_v3.txt).
+// against 3 + ~12 us now, profiles/r01_cornell_1080p_64spp_kernel_stats_v3.txt); packing a workgroup's camera and
+// material slots through LDS so that whole waves run only generate or only shade (47.3 -> 47.5 us at 2 M slots: no gain).
 // ============================================================================================
 __device__ __forceinline__ int4 wave_sum4(int4 v) {
     for (int off = 32; off > 0; off >>= 1)
