@@ -372,7 +372,7 @@ int pt_render_init(pt_ctx* c, const pt_render_params* p) {
     size_t img_floats = (size_t)p->width * p->height * 4;
     if (p->image_dev) { c->d_image = (float*)p->image_dev; c->own_image = false; HIPOK(c, hipMemsetAsync(c->d_image, 0, img_floats * 4, c->stream)); }
     else { if ((r = ralloc(c, &c->d_image, img_floats))) return r; c->own_image = true; }
-    HIPOK(c, hipHostMalloc((void**)&c->h_hdr, sizeof(StepHeader), hipHostMallocDefault));
+    HIPOK(c, hipHostMalloc((void**)&c->h_hdr, 2 * sizeof(StepHeader), hipHostMallocDefault));
     {   // the pixel-independent part of the camera: evaluated by the device (same arithmetic as every other kernel), kept in rc
         CameraFrame* d_cf = nullptr;
         if ((r = dalloc(c, &d_cf, 1, true))) return r;
@@ -416,28 +416,49 @@ int pt_render_run(pt_ctx* c, int64_t max_steps, int flags, pt_run_stats* out) {
     HIPOK(c, hipSetDevice(c->device));
     const int POLL = 8;   // steps between looks at the queue sizes (the reference never looks: main.js:61-72)
     bool timed = (flags & PT_RUN_TIME_EXTEND) != 0; int count = (flags & PT_RUN_COUNT_BYTES) ? 1 : 0;
-    if (timed && c->events.empty()) {
-        c->events.resize(2);
+    if (c->events.empty()) {   // per batch parity: [0,1] bracket a timed extend launch, [2] marks "header copy landed"
+        c->events.resize(6);
         for (hipEvent_t& e : c->events) HIPOK(c, hipEventCreate(&e));
     }
-    // PT_RUN_TIME_EXTEND: one extend launch per batch of POLL steps is bracketed by events, at a position that rotates
-    // through the batch.  (Events around every launch were measured to cost 5.5 % of the render: each record is a barrier
-    // packet between two kernels of a 120 us step.)
-    double extend_ms = 0.0; int64_t launches = 0, issued = 0, batch = 0;
+    // Batches of POLL steps are issued one ahead of the host's look at the queue sizes: batch b+1 is on the stream before
+    // the host waits for the header copy that followed batch b, so the GPU never idles for the read-back (a render ends
+    // with up to 2*POLL - 1 empty steps of ~15 us instead).
+    // PT_RUN_TIME_EXTEND: one extend launch per batch is bracketed by events, at a position that rotates through the
+    // batch.  (Events around every launch were measured to cost 5.5 % of the render: each record is a barrier packet
+    // between two kernels of a 120 us step.)
+    double extend_ms = 0.0; int64_t launches = 0, issued = 0;
     if (max_steps <= 0) max_steps = INT64_MAX;
-    for (;; batch++) {
-        int k = 0, timed_k = -1;
-        for (; k < POLL && issued < max_steps; k++, issued++) {
+    bool had_timed[2] = {false, false};
+    auto issue = [&](int64_t batch) -> int {
+        int p = (int)(batch & 1); had_timed[p] = false;
+        for (int k = 0; k < POLL && issued < max_steps; k++, issued++) {
             bool t = timed && k == (int)(batch % POLL);
-            if (t) timed_k = k;
-            enqueue_step(c, count, t ? c->events[0] : nullptr, t ? c->events[1] : nullptr);
+            if (t) had_timed[p] = true;
+            enqueue_step(c, count, t ? c->events[3 * p] : nullptr, t ? c->events[3 * p + 1] : nullptr);
         }
         HIPOK(c, hipGetLastError());
-        int r = read_back(c, c->h_hdr, c->d_hdr, sizeof(StepHeader));
-        if (r) return r;
-        if (timed_k >= 0) { float ms = 0; HIPOK(c, hipEventElapsedTime(&ms, c->events[0], c->events[1])); extend_ms += ms; launches++; }
-        if (c->h_hdr->first_empty_step >= 0 || issued >= max_steps) break;
+        HIPOK(c, hipMemcpyAsync(c->h_hdr + p, c->d_hdr, sizeof(StepHeader), hipMemcpyDeviceToHost, c->stream));
+        HIPOK(c, hipEventRecord(c->events[3 * p + 2], c->stream));
+        return PT_OK;
+    };
+    auto collect = [&](int64_t batch) -> int {
+        int p = (int)(batch & 1);
+        HIPOK(c, hipEventSynchronize(c->events[3 * p + 2]));
+        if (had_timed[p]) { float ms = 0; HIPOK(c, hipEventElapsedTime(&ms, c->events[3 * p], c->events[3 * p + 1])); extend_ms += ms; launches++; }
+        return PT_OK;
+    };
+    int r = issue(0); if (r) return r;
+    int64_t last = 0;   // last batch issued
+    for (int64_t b = 0;; b++) {
+        bool more = issued < max_steps;
+        if (more) { if ((r = issue(b + 1))) return r; last = b + 1; }
+        if ((r = collect(b))) return r;
+        if (c->h_hdr[b & 1].first_empty_step >= 0 || !more) {
+            if (last > b && (r = collect(last))) return r;    // drain the batch issued ahead
+            break;
+        }
     }
+    if (last & 1) c->h_hdr[0] = c->h_hdr[1];                   // the final header lives in h_hdr[0] for the code below
     if (c->h_hdr->first_empty_step < 0) {   // stopped by max_steps: bring the image up to date for the caller
         ptk_flush_tickets(c->ps, c->rc.num_paths, c->d_image, c->stream);
         HIPOK(c, hipStreamSynchronize(c->stream));
