@@ -205,6 +205,75 @@ def test_multi_gpu_partition_on_one_gpu(pta, orc, device, built):
     np.testing.assert_array_equal(acc[..., 3], np.full((h, w), spp))
 
 
+@pytest.mark.parametrize("paths", [1, 63, 64, 65, 255, 257, 1023, 1024, 1025, 2049])
+def test_pool_sizes_around_the_workgroup_boundaries(pta, orc, device, built, paths):
+    """Slot pools that are not a multiple of the wave (64), of the compaction workgroup (256) or of the count record
+    (1024): queues, tickets and the finished frame still match the oracle (empty, ragged and exactly-full tails)."""
+    desc, s, o = built("cornell")
+    w, h, spp = 24, 16, 16
+    pt = pta.init_path_tracer({"device": device, "scene": s, "image": {"width": w, "height": h}, "camera": desc["camera"],
+                               "settings": {"samples": spp, "numPaths": paths}})
+    orr = orc.OrcRender(o, w, h, desc["camera"], spp, paths)
+    for step in range(3):
+        gs = pt.step(); cs = orr.step_like_device()
+        assert (gs.n_camera, gs.n_material) == (cs.n_camera, cs.n_material)
+        np.testing.assert_array_equal(pt.queue(0), orr.queue(0)); np.testing.assert_array_equal(pt.queue(1), orr.queue(1))
+        assert_state_equal(pt, orr, step)
+    rs = pt.run(max_steps=200000)
+    while orr.step_like_device().n_rays:
+        pass
+    img_g, img_c = pt.read_image(), orr.image()
+    np.testing.assert_array_equal(img_g[..., 3], np.full((h, w), spp, np.float32))
+    np.testing.assert_allclose(img_g[..., :3], img_c[..., :3], rtol=1e-5, atol=1e-6)
+    assert rs.total_samples == w * h * spp and rs.stack_overflows == 0
+
+
+def test_run_again_and_reset(pta, orc, device, built):
+    """run() on a finished render traces nothing more; reset() + run() reproduces the frame (sample counts exactly, radiance
+    to the atomic-order tolerance); a render stopped by max_steps can be continued to the same result."""
+    desc, s, o = built("cornell")
+    w, h, spp, paths = 64, 36, 16, 3000
+    pt = pta.init_path_tracer({"device": device, "scene": s, "image": {"width": w, "height": h}, "camera": desc["camera"],
+                               "settings": {"samples": spp, "numPaths": paths}})
+    r1 = pt.run(); img1 = pt.read_image().copy()
+    r2 = pt.run()
+    assert (r2.total_rays, r2.total_samples) == (r1.total_rays, r1.total_samples)
+    np.testing.assert_array_equal(pt.read_image(), img1)
+    pt.reset()
+    r3 = pt.run(max_steps=5)
+    assert r3.steps == 5 and r3.total_rays < r1.total_rays
+    partial = pt.read_image()
+    assert 0 < partial[..., 3].sum() < w * h * spp
+    r4 = pt.run()
+    assert (r4.steps, r4.total_rays, r4.total_samples) == (r1.steps, r1.total_rays, r1.total_samples)
+    img2 = pt.read_image()
+    np.testing.assert_array_equal(img2[..., 3], img1[..., 3])
+    np.testing.assert_allclose(img2[..., :3], img1[..., :3], rtol=1e-5, atol=1e-6)
+
+
+def test_wave_log_hook(pta, device, built):
+    """pt_extend_wave_log: one record per launched wave, end >= start, classes and trip counts plausible, and the replay
+    leaves the render's results alone."""
+    import ctypes as C
+    desc, s, o = built("cornell")
+    paths = 5000
+    pt = pta.init_path_tracer({"device": device, "scene": s, "image": {"width": 96, "height": 54}, "camera": desc["camera"],
+                               "settings": {"samples": 16, "numPaths": paths}})
+    for _ in range(4):
+        st = pt.step()
+    cap = (paths + 63) // 64 + 4
+    buf = np.zeros((cap, 4), np.uint64); n = C.c_int64()
+    device.call("pt_extend_wave_log", 2, buf.ctypes.data_as(C.c_void_p), cap, C.byref(n))
+    log = buf[: n.value]; live = log[log[:, 1] != 0]
+    assert n.value == (paths + 63) // 64 and len(live) == (st.n_rays + 63) // 64
+    assert np.all(live[:, 1] >= live[:, 0])
+    cls = (live[:, 3] >> np.uint64(24)) & np.uint64(0xff); trips = live[:, 3] & np.uint64(0xffffff)
+    assert set(np.unique(cls).tolist()) <= {0, 1} and trips.max() >= 3
+    img_before = pt.read_image().copy()
+    pt.run()
+    assert pt.read_image()[..., 3].sum() == 96 * 54 * 16 and img_before[..., 3].sum() <= 96 * 54 * 16
+
+
 def test_error_behaviour(pta, device):
     """Reference: console.warn + undefined (scene.js:149,525); here: negative status + message."""
     dev2 = pta.request_device(0)
