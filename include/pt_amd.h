@@ -105,6 +105,23 @@ int pt_render_init(pt_ctx* ctx, const pt_render_params* params);
  * again, as a second initPathTracer() call would find them (new GPUBuffers are zero-filled). */
 int pt_render_reset(pt_ctx* ctx);
 
+/* ---- extensions (NO reference counterpart: the reference has two grey Lambert materials, a hard-coded bounce
+ * cut and no seed -- material.js:106-111, logic.js:111, logic.js:77).  Default-off: without this call, or with an all-zero
+ * pt_render_ext, every result is the reference's.  The rules are defined by the oracle (oracle/pt_oracle.h) and reproduced
+ * bit for bit by the kernels.  Call after pt_render_init (or pt_render_reset) and before the first step; it survives
+ * pt_render_reset.
+ *   max_nb     replaces the 20 of logic.js:111 (num_bounces advances by 2 per bounce there); 0 keeps 20
+ *   seed       decorrelates the random streams: added (times 0x9E3779B1 mod 2^32) to the slot index hashed at logic.js:77
+ *   materials  materials[k] describes material id k + 2; ids 0 and 1 stay the reference's; an id without an entry keeps the
+ *              reference's unknown-id behaviour (zero BRDF)
+ *                PT_MAT_LAMBERT  rgb albedo (linear), the reference's cosine sampling
+ *                PT_MAT_EMITTER  the path ends at the hit and adds throughput * emission
+ *                PT_MAT_MIRROR   wi = d - 2 (d.n) n, throughput *= albedo */
+enum { PT_MAT_LAMBERT = 0, PT_MAT_EMITTER = 1, PT_MAT_MIRROR = 2, PT_MAX_EXT_MATERIALS = 14 };
+typedef struct { float albedo[3]; int32_t type; float emission[3]; int32_t pad; } pt_material;   /* 32 B */
+typedef struct { int32_t max_nb; uint32_t seed; int32_t n_materials, pad; pt_material materials[PT_MAX_EXT_MATERIALS]; } pt_render_ext;
+int pt_render_set_extensions(pt_ctx* ctx, const pt_render_ext* ext);
+
 typedef struct {
     int64_t n_camera;     /* stage_2_queue_size[0] after logic (path-tracer.js:174) */
     int64_t n_material;   /* stage_2_queue_size[1] */

@@ -525,6 +525,7 @@ struct orc_render {
     float* image; float* contrib; uint8_t* code;
     int32_t *camera_queue, *material_queue; int64_t n_camera, n_material;
     int64_t total_rays, traversal_bytes;
+    orc_render_ext ext;
 };
 
 orc_render* orc_render_create(const orc_scene* s, const orc_render_params* p) {
@@ -543,6 +544,7 @@ orc_render* orc_render_create(const orc_scene* s, const orc_render_params* p) {
     r->ticket_limit  = p->ticket_end >= 0 ? p->ticket_end : total;
     return r;
 }
+void orc_render_set_extensions(orc_render* r, const orc_render_ext* e) { r->ext = *e; }
 void orc_render_destroy(orc_render* r) {
     if (!r) return;
     free(r->pixel_index); free(r->num_bounces); free(r->hit_obj); free(r->hit_tri); free(r->samples_in_pixel); free(r->flags);
@@ -556,7 +558,7 @@ static void logic_slot(orc_render* r, int64_t i, int first_sample) {
     uint8_t code = 0; float* c = r->contrib + 4 * i; c[0] = c[1] = c[2] = c[3] = 0.0f;
     if ((r->flags[i] & (1u << 31)) != 0u) { r->code[i] = 0; return; }
     if (first_sample) {
-        uint32_t gi = (uint32_t)(r->p.slot_base + i);
+        uint32_t gi = (uint32_t)(r->p.slot_base + i) + r->ext.seed * 0x9E3779B1u;   /* ext: user seed (0 = reference) */
         r->random_seed[i] = (float)orc_base_hash(gi, gi + 1u) / 4294967296.0f + 0.008f; /* :77 */
         r->path_throughput[4 * i] = r->path_throughput[4 * i + 1] = r->path_throughput[4 * i + 2] = 1.0f;
         code = 1 | 4;
@@ -565,7 +567,10 @@ static void logic_slot(orc_render* r, int64_t i, int first_sample) {
         int32_t nb = r->num_bounces[i] + 1;
         int b_hit = r->hit_obj[i] >= 0;
         uint32_t flags = r->flags[i];
-        if (flags & 1u) {
+        if (flags & 2u) {                /* ext: the ray hit an emitter -- add throughput * emission, end the path */
+            v3 e = v3_mul(tp, v3_ld(r->material_throughput_pdf + 4 * i));
+            c[0] += e.x; c[1] += e.y; c[2] += e.z; tp = V3(0, 0, 0);
+        } else if (flags & 1u) {
             tp = v3_mul(tp, v3_ld(r->material_throughput_pdf + 4 * i));
             if (nb > 3) {
                 float r0, r1; orc_rand2(r->random_seed[i], &r0, &r1); (void)r1;
@@ -574,7 +579,7 @@ static void logic_slot(orc_render* r, int64_t i, int first_sample) {
                 if (r0 < q) tp = V3(0, 0, 0); else tp = v3_divs(tp, 1.0f - q);
             }
         }
-        if (nb > 20) tp = V3(0, 0, 0);
+        if (nb > (r->ext.max_nb > 0 ? r->ext.max_nb : 20)) tp = V3(0, 0, 0);   /* :111; ext: max_nb */
         if (!b_hit) { c[0] += 2.0f * tp.x; c[1] += 2.0f * tp.y; c[2] += 2.0f * tp.z; tp = V3(0, 0, 0); }
         if (tp.x == 0.0f && tp.y == 0.0f && tp.z == 0.0f) {
             c[3] = 1.0f; code |= 1; nb = 0; tp = V3(1, 1, 1);
@@ -651,8 +656,29 @@ static void material_slot(orc_render* r, int32_t path) {
         bp[0] = bp[1] = bp[2] = a; bp[3] = wi.z;
     }
     v3 nd = v3_add(v3_add(v3_scale(o1, wi.x), v3_scale(o2, wi.y)), v3_scale(n, wi.z));
+    uint32_t flag = 1u;
+    if (mat >= 2 && mat - 2 < r->ext.n_materials) {              /* ext materials (pt_oracle.h); nothing of the reference below */
+        const orc_material* m = &r->ext.materials[mat - 2];
+        if (m->type == ORC_MAT_LAMBERT) {
+            float r0, r1; orc_rand2(seed, &r0, &r1); seed += 2.0f;
+            float rad = sqrtf(fmaxf(r0, 0.0f)), theta = 6.283185307179586f * r1, sn, cs;
+            orc_sincos(theta, &sn, &cs);
+            float dx = rad * cs, dy = rad * sn;
+            float z = sqrtf(fmaxf(0.0f, (1.0f - dx * dx) - dy * dy));
+            wi = V3(dx, dy, z);
+            bp[0] = m->albedo[0]; bp[1] = m->albedo[1]; bp[2] = m->albedo[2]; bp[3] = wi.z;
+            nd = v3_add(v3_add(v3_scale(o1, wi.x), v3_scale(o2, wi.y)), v3_scale(n, wi.z));
+        } else if (m->type == ORC_MAT_EMITTER) {
+            bp[0] = m->emission[0]; bp[1] = m->emission[1]; bp[2] = m->emission[2]; bp[3] = 0.0f;
+            nd = n; flag = 3u;                                   /* the ray is traced but its result is ignored */
+        } else if (m->type == ORC_MAT_MIRROR) {
+            float k = 2.0f * v3_dot(d, n);
+            nd = v3_sub(d, v3_scale(n, k));
+            bp[0] = m->albedo[0]; bp[1] = m->albedo[1]; bp[2] = m->albedo[2]; bp[3] = 1.0f;
+        }
+    }
     memcpy(r->material_throughput_pdf + 4 * path, bp, 16);
-    r->flags[path] |= 1u;
+    r->flags[path] |= flag;
     r->random_seed[path] = seed;
     v3 no = v3_add(hit_pos, v3_scale(n, 0.0001f));
     float* po = r->path_o + 4 * path; float* pd = r->path_d + 4 * path;

@@ -98,9 +98,24 @@ typedef struct {
 
 typedef struct { int64_t n_camera, n_material, n_rays, n_live; } orc_step_stats;
 
+/* ---- extensions: things the configs ask for that the reference does not have.  All default-off: with
+ * max_nb = 0, seed = 0 and no extension materials every result is the reference's.  There is nothing in the reference
+ * to follow here; the oracle DEFINES these rules and the HIP kernels must reproduce them.
+ *   max_nb   replaces the constant of logic.js:111 (num_bounces advances by 2 per bounce there; 0 -> 20)
+ *   seed     added (times 0x9E3779B1, mod 2^32) to the global slot index hashed at logic.js:77
+ *   materials[k] describes material id k + 2 (ids 0 and 1 stay the reference's two grey Lambert albedos, material.js:106-111;
+ *   an id with no entry keeps the reference's behaviour for unknown ids: zero BRDF, the path dies)
+ *     type 0 Lambert, rgb albedo already in linear space (same cosine sampling as the reference)
+ *     type 1 emitter: the path ends at the hit and adds throughput * emission
+ *     type 2 mirror: wi = d - 2 (d.n) n, throughput *= albedo */
+enum { ORC_MAT_LAMBERT = 0, ORC_MAT_EMITTER = 1, ORC_MAT_MIRROR = 2, ORC_MAX_EXT_MATERIALS = 14 };
+typedef struct { float albedo[3]; int32_t type; float emission[3]; int32_t pad; } orc_material;       /* 32 B */
+typedef struct { int32_t max_nb; uint32_t seed; int32_t n_materials, pad; orc_material materials[ORC_MAX_EXT_MATERIALS]; } orc_render_ext;
+
 typedef struct orc_render orc_render;
 orc_render* orc_render_create(const orc_scene*, const orc_render_params*);
 void        orc_render_destroy(orc_render*);
+void        orc_render_set_extensions(orc_render*, const orc_render_ext*);   /* before the first step */
 void        orc_render_step(orc_render*, orc_step_stats* out, int threads);
 /* the four dispatches of a step, one at a time (step = LOGIC, QUEUES_CAMERA, MATERIAL, TRACE; QUEUES_CAMERA and MATERIAL
  * touch disjoint slots and may be swapped) */

@@ -38,6 +38,18 @@ class PtRunStats(C.Structure):
                 ("traversal_bytes", C.c_int64)]
 
 
+PT_MAT_LAMBERT, PT_MAT_EMITTER, PT_MAT_MIRROR, PT_MAX_EXT_MATERIALS = 0, 1, 2, 14
+
+
+class PtMaterial(C.Structure):
+    _fields_ = [("albedo", C.c_float * 3), ("type", C.c_int32), ("emission", C.c_float * 3), ("pad", C.c_int32)]
+
+
+class PtRenderExt(C.Structure):
+    _fields_ = [("max_nb", C.c_int32), ("seed", C.c_uint32), ("n_materials", C.c_int32), ("pad", C.c_int32),
+                ("materials", PtMaterial * PT_MAX_EXT_MATERIALS)]
+
+
 # name -> (restype, argtypes); every symbol include/pt_amd.h declares
 SIGNATURES = {
     "pt_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
@@ -57,6 +69,7 @@ SIGNATURES = {
     "pt_trace_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pt_render_init": (C.c_int, [C.c_void_p, C.POINTER(PtRenderParams)]),
     "pt_render_reset": (C.c_int, [C.c_void_p]),
+    "pt_render_set_extensions": (C.c_int, [C.c_void_p, C.POINTER(PtRenderExt)]),
     "pt_render_step": (C.c_int, [C.c_void_p, C.POINTER(PtStepStats)]),
     "pt_render_run": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.POINTER(PtRunStats)]),
     "pt_image_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),

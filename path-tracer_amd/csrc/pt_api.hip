@@ -40,6 +40,7 @@ struct pt_ctx {
     float* d_image = nullptr; bool own_image = false; uint8_t* d_code = nullptr;
     int4 *d_blk_counts = nullptr; int32_t *d_cam_q = nullptr, *d_mat_q = nullptr, *d_spill = nullptr;
     StepHeader* d_hdr = nullptr; StepHeader* h_hdr = nullptr; int nblocks = 0; int64_t step = 0;
+    float4* d_ext_mats = nullptr; int n_ext_mats = 0;   // extension materials (pt_render_set_extensions)
     std::vector<std::pair<void*, size_t>> render_allocs; std::vector<hipEvent_t> events; int64_t ticket_begin = 0;
 };
 
@@ -64,7 +65,11 @@ template <typename T> int dalloc(pt_ctx* c, T** p, size_t count, bool zero) {
 }
 void dfree(void* p) { if (p) (void)hipFree(p); }
 
-SceneView scene_view(const pt_ctx* c) { SceneView v; v.tlas = c->d_tlas_nodes; v.objects = c->d_objects; v.blas = c->d_blas_nodes; v.tris = c->d_blas_tris; return v; }
+SceneView scene_view(const pt_ctx* c) {
+    SceneView v; v.tlas = c->d_tlas_nodes; v.objects = c->d_objects; v.blas = c->d_blas_nodes; v.tris = c->d_blas_tris;
+    v.ext_mats = c->d_ext_mats; v.n_ext_mats = c->n_ext_mats; v.pad = 0;
+    return v;
+}
 
 // builders.js:174-192: sort -> radix tree -> up pass.  aabb: 2 quads per primitive; keys are consumed.
 int build_bvh(pt_ctx* c, const float4* d_aabb, uint32_t* d_keys, int64_t n, int32_t* d_perm_out, float4* d_nodes_out) {
@@ -114,6 +119,8 @@ void free_render(pt_ctx* c) {
     if (c->h_hdr) { (void)hipHostFree(c->h_hdr); c->h_hdr = nullptr; }
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     c->events.clear();
+    if (c->d_ext_mats) { dfree(c->d_ext_mats); c->d_ext_mats = nullptr; }
+    c->n_ext_mats = 0;
     c->render_ready = false; c->d_image = nullptr;
 }
 
@@ -356,6 +363,8 @@ int pt_render_init(pt_ctx* c, const pt_render_params* p) {
     int64_t total = ((int64_t)p->width * p->height * p->spp + PT_SAMPLES_PER_TICKET - 1) / PT_SAMPLES_PER_TICKET;   // logic.js:177
     rc.slot_base = p->slot_base;
     rc.ticket_limit = p->ticket_end >= 0 ? p->ticket_end : total;
+    rc.max_nb = 20; rc.seed_mix = 0u;            // logic.js:111, :77 -- the reference's rules until pt_render_set_extensions says otherwise
+    c->n_ext_mats = 0;
     c->ticket_begin = p->ticket_end >= 0 ? p->ticket_begin : 0;
     int r; size_t n = (size_t)np;
     PathState& ps = c->ps;   // zero-filled like a new GPUBuffer (path-tracer.js:271-275)
@@ -384,6 +393,26 @@ int pt_render_init(pt_ctx* c, const pt_render_params* p) {
     }
     c->render_ready = true;
     return write_header(c);
+}
+
+int pt_render_set_extensions(pt_ctx* c, const pt_render_ext* e) {
+    if (!c || !e) return fail(c, PT_ERR_ARG, "pt_render_set_extensions: null argument");
+    if (!c->render_ready) return fail(c, PT_ERR_STATE, "pt_render_set_extensions: pt_render_init has not been called");
+    if (c->step != 0) return fail(c, PT_ERR_STATE, "pt_render_set_extensions: the render has started; call pt_render_reset first");
+    if (e->max_nb < 0 || e->n_materials < 0 || e->n_materials > PT_MAX_EXT_MATERIALS) return fail(c, PT_ERR_ARG, "pt_render_set_extensions: bad max_nb or n_materials");
+    for (int k = 0; k < e->n_materials; k++)
+        if (e->materials[k].type < 0 || e->materials[k].type > PT_MAT_MIRROR) return fail(c, PT_ERR_ARG, "pt_render_set_extensions: unknown material type");
+    HIPOK(c, hipSetDevice(c->device));
+    c->rc.max_nb = e->max_nb > 0 ? e->max_nb : 20;
+    c->rc.seed_mix = e->seed * 0x9E3779B1u;
+    if (e->n_materials > 0) {
+        int r;
+        if (!c->d_ext_mats && (r = dalloc(c, &c->d_ext_mats, (size_t)2 * PT_MAX_EXT_MATERIALS, true))) return r;   // survives pt_render_reset
+        HIPOK(c, hipMemcpyAsync(c->d_ext_mats, e->materials, sizeof(pt_material) * e->n_materials, hipMemcpyHostToDevice, c->stream));
+        HIPOK(c, hipStreamSynchronize(c->stream));
+    }
+    c->n_ext_mats = e->n_materials;
+    return PT_OK;
 }
 
 int pt_render_reset(pt_ctx* c) {

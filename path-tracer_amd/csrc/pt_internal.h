@@ -19,6 +19,8 @@ struct SceneView {
     const float4* objects;   // pt_object[n_objects]
     const float4* blas;      // pt_bvh_node[n_tris]
     const float4* tris;      // pt_triangle[n_tris]
+    const float4* ext_mats;  // extension materials (pt_material = 2 quads each) for material ids 2.., null by default
+    int32_t n_ext_mats, pad;
 };
 
 // PathState (path-tracer.js:131-160) as separate device arrays; vec3f members keep the
@@ -65,6 +67,8 @@ struct RenderConst {
     float   cam_pos[3], cam_look_at[3], fov_deg;
     int64_t slot_base, ticket_limit;
     CameraFrame frame;
+    int32_t max_nb;      // logic.js:111 constant (20) unless the max_nb extension is set
+    uint32_t seed_mix;   // 0 unless the seed extension is set
 };
 
 // ---- launchers (pt_kernels_build.hip) ---------------------------------------------------------
@@ -91,7 +95,7 @@ void ptk_count_compact_generate_shade(const PathState& ps, const RenderConst& rc
 // count != 0 selects the visit-counting variant.
 void ptk_extend_queue(const PathState& ps, const RenderConst& rc, const SceneView& sc, StepHeader* hdr,
                       const int32_t* cam_q, const int32_t* mat_q, int32_t* spill, int count, int variant,
-                      unsigned long long* wave_log /* null unless measuring */, float* image, uint8_t* code, hipStream_t s);
+                      unsigned long long* wave_log /* null unless measuring */, float* image, uint8_t* code, hipStream_t s);   // uses rc.max_nb
 int64_t ptk_extend_waves(int num_paths, int variant);   // waves the launch of that variant holds (wave_log entries)
 int ptk_extend_num_variants();
 const char* ptk_extend_variant_name(int v);

@@ -162,7 +162,8 @@ __device__ __forceinline__ void publish(unsigned long long ov, unsigned long lon
 template <int LDS_N, int BLOCK, bool COUNT, int ORDER, bool LOG, bool LOGIC>
 __global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView sc, StepHeader* hdr, const int32_t* __restrict__ cam_q,
                                                         const int32_t* __restrict__ mat_q, int32_t* spill, int64_t spill_stride,
-                                                        unsigned long long* wave_log, float* __restrict__ image, uint8_t* __restrict__ code_out) {
+                                                        unsigned long long* wave_log, float* __restrict__ image, uint8_t* __restrict__ code_out,
+                                                        int max_nb) {
     unsigned long long t_start = LOG ? wall_clock64() : 0;
     __shared__ int s_stack[LDS_N * BLOCK];
     int n_cam = hdr->n_camera, n_rays = n_cam + hdr->n_material;
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView 
         trav_finish<COUNT>(sc, r);
         ps.hit_obj[path] = r.hit_obj; ps.hit_tri[path] = r.hit_tri;
         if (LOGIC) {
-            unsigned code = logic_one(ps, image, path, r.hit_obj >= 0);
+            unsigned code = logic_one(ps, image, path, r.hit_obj >= 0, max_nb);
             code_out[path] = (uint8_t)code;
         }
     }
@@ -236,11 +237,12 @@ size_t ptk_spill_ints(int64_t n_rays) { return (size_t)pad_to(n_rays, 256) * (PT
 
 template <int LDS_N, int BLOCK, int ORDER>
 static void launch_queue(const PathState& ps, int num_paths, const SceneView& sc, StepHeader* hdr, const int32_t* cam_q,
-                         const int32_t* mat_q, int32_t* spill, int count, unsigned long long* wave_log, float* image, uint8_t* code, hipStream_t s) {
+                         const int32_t* mat_q, int32_t* spill, int count, unsigned long long* wave_log, float* image, uint8_t* code, int max_nb,
+                         hipStream_t s) {
     int64_t stride = pad_to(num_paths, 256);
     dim3 grid((unsigned)((num_paths + BLOCK - 1) / BLOCK));
 #define PT_LAUNCH(COUNT, LOG, LOGIC) hipLaunchKernelGGL((k_extend_queue<LDS_N, BLOCK, COUNT, ORDER, LOG, LOGIC>), grid, dim3(BLOCK), 0, s, ps, sc, hdr, \
-                                                       cam_q, mat_q, spill, stride, wave_log, image, code)
+                                                       cam_q, mat_q, spill, stride, wave_log, image, code, max_nb)
     if (wave_log)    PT_LAUNCH(false, true, false);    // measurement replays (code == null): traversal only, idempotent
     else if (!code)  PT_LAUNCH(false, false, false);
     else if (count)  PT_LAUNCH(true, false, true);
@@ -268,9 +270,9 @@ const char* ptk_extend_variant_name(int v) { return (v >= 0 && v < 3) ? kVariant
 void ptk_extend_queue(const PathState& ps, const RenderConst& rc, const SceneView& sc, StepHeader* hdr, const int32_t* cam_q,
                       const int32_t* mat_q, int32_t* spill, int count, int variant, unsigned long long* wave_log, float* image, uint8_t* code,
                       hipStream_t s) {
-    if (variant == 0)      launch_queue<24, 256, 1>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, s);
-    else if (variant == 1) launch_queue<16, 64, 1>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, s);
-    else                   launch_queue<16, 64, 2>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, s);
+    if (variant == 0)      launch_queue<24, 256, 1>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rc.max_nb, s);
+    else if (variant == 1) launch_queue<16, 64, 1>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rc.max_nb, s);
+    else                   launch_queue<16, 64, 2>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rc.max_nb, s);
 }
 int64_t ptk_extend_waves(int num_paths, int variant) {
     int block = variant == 0 ? 256 : 64;

@@ -26,7 +26,7 @@ __device__ __forceinline__ int4 add4(int4 a, int4 b) { return make_int4(a.x + b.
 __global__ __launch_bounds__(PT_BLOCK) void k_first_logic(PathState ps, RenderConst rc, uint8_t* __restrict__ code_out) {
     int i = blockIdx.x * PT_BLOCK + threadIdx.x;
     if (i >= rc.num_paths) return;
-    uint32_t gi = (uint32_t)(rc.slot_base + i);
+    uint32_t gi = (uint32_t)(rc.slot_base + i) + rc.seed_mix;              // seed_mix: 0 unless the seed extension is set
     ps.random_seed[i] = (float)base_hash(gi, gi + 1u) * 2.3283064365386962890625e-10f + 0.008f;   // logic.js:77
     ps.path_throughput[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
     code_out[i] = (uint8_t)(PT_CODE_CAMERA | PT_CODE_TICKET);

@@ -56,10 +56,6 @@ __device__ __forceinline__ CameraFrame camera_frame(const RenderConst& rc) {
 // ============================================================================================
 // shade (material.js:75-120; scene.js:204-258 get_triangle_hit_info)
 // ============================================================================================
-// STAGED: the three groups of loads (world-to-local rows, triangle, local-to-world rows) are issued one after the other
-// instead of all up front, which keeps the live registers under the extend kernel's 64 (8 waves per SIMD); the arithmetic
-// is the same.
-template <bool STAGED = false>
 __device__ __forceinline__ void shade_one(const PathState& ps, const SceneView& sc, int path, int hit_obj, int hit_tri) {
     f3 o = F3(ps.path_o[path]), d = F3(ps.path_d[path]);
     const float4* ob = sc.objects + 8 * (int64_t)hit_obj;
@@ -69,7 +65,6 @@ __device__ __forceinline__ void shade_one(const PathState& ps, const SceneView& 
         lo = xform(w0, w1, w2, o, 1.0f); ld = xform(w0, w1, w2, d, 0.0f);
         mat = __float_as_int(inf.y);
     }
-    if (STAGED) asm volatile("" ::: "memory");
     f3 ln, lhit;
     {
         const float4* tr = sc.tris + 3 * (int64_t)hit_tri;
@@ -82,7 +77,6 @@ __device__ __forceinline__ void shade_one(const PathState& ps, const SceneView& 
         float ldist = dot3(v0v2, qvec) * i_det;
         lhit = lo + ld * ldist;
     }
-    if (STAGED) asm volatile("" ::: "memory");
     float4 l0 = ob[0], l1 = ob[1], l2 = ob[2];
     f3 whit = xform(l0, l1, l2, lhit, 1.0f);
     f3 n = normalize3(xform(l0, l1, l2, ln, 0.0f));
@@ -103,9 +97,30 @@ __device__ __forceinline__ void shade_one(const PathState& ps, const SceneView& 
         bp = make_float4(a, a, a, wi.z);
     }
     f3 nd = (o1 * wi.x + o2 * wi.y) + n * wi.z;
+    unsigned flag = 1u;
+    if (mat >= 2 && mat - 2 < sc.n_ext_mats) {                                  // extension materials: rules defined in oracle/pt_oracle.h
+        float4 m0 = sc.ext_mats[2 * (mat - 2)], m1 = sc.ext_mats[2 * (mat - 2) + 1];
+        int type = __float_as_int(m0.w);
+        if (type == 0) {                                                        // Lambert, rgb albedo
+            float2 r2 = rand2(seed); seed += 2.0f;
+            float rad = __builtin_sqrtf(fmax_(r2.x, 0.0f)), sn, cs;
+            pt_sincos(6.283185307179586f * r2.y, sn, cs);
+            float dx = rad * cs, dy = rad * sn;
+            float z = __builtin_sqrtf(fmax_(0.0f, (1.0f - dx * dx) - dy * dy));
+            wi = F3(dx, dy, z);
+            bp = make_float4(m0.x, m0.y, m0.z, wi.z);
+            nd = (o1 * wi.x + o2 * wi.y) + n * wi.z;
+        } else if (type == 1) {                                                 // emitter
+            bp = make_float4(m1.x, m1.y, m1.z, 0.0f); nd = n; flag = 3u;
+        } else if (type == 2) {                                                 // mirror
+            float k = 2.0f * dot3(d, n);
+            nd = d - n * k;
+            bp = make_float4(m0.x, m0.y, m0.z, 1.0f);
+        }
+    }
     f3 no = hit_pos + n * 0.0001f;
     ps.material_throughput_pdf[path] = bp;
-    ps.flags[path] |= 1u;
+    ps.flags[path] |= flag;
     ps.random_seed[path] = seed;
     ps.path_o[path] = make_float4(no.x, no.y, no.z, 0.0f);
     ps.path_d[path] = make_float4(nd.x, nd.y, nd.z, 0.0f);
@@ -118,14 +133,16 @@ __device__ __forceinline__ void shade_one(const PathState& ps, const SceneView& 
 // of one per sample (scattered float atomics are the slowest memory operation on this chip).  The reference's
 // own add order is a race (logic.js:222-233); sample counts stay exact.
 // ============================================================================================
-__device__ __forceinline__ unsigned logic_one(const PathState& ps, float* __restrict__ image, int i, bool b_hit) {
+__device__ __forceinline__ unsigned logic_one(const PathState& ps, float* __restrict__ image, int i, bool b_hit, int max_nb) {
     unsigned code = 0; bool finished = false;
     if ((ps.flags[i] & (1u << 31)) != 0u) return 0u;                             // logic.js:66 a slot past the last ticket
     f3  tp = F3(ps.path_throughput[i]);
     int nb = ps.num_bounces[i] + 1;
     uint32_t flags = ps.flags[i];
     f3 contrib = F3(0.0f, 0.0f, 0.0f);
-    if (flags & 1u) {                                                   // logic.js:94-109
+    if (flags & 2u) {                                                   // extension: the ray hit an emitter (pt_amd.h pt_material)
+        contrib = tp * F3(ps.material_throughput_pdf[i]); tp = F3(0.0f, 0.0f, 0.0f);
+    } else if (flags & 1u) {                                            // logic.js:94-109
         tp = tp * F3(ps.material_throughput_pdf[i]);
         if (nb > 3) {
             float seed = ps.random_seed[i];
@@ -135,8 +152,8 @@ __device__ __forceinline__ unsigned logic_one(const PathState& ps, float* __rest
             if (r2.x < q) tp = F3(0.0f, 0.0f, 0.0f); else tp = tp / (1.0f - q);
         }
     }
-    if (nb > 20) tp = F3(0.0f, 0.0f, 0.0f);                              // logic.js:111-113
-    if (!b_hit) { contrib = F3(0.0f + 2.0f * tp.x, 0.0f + 2.0f * tp.y, 0.0f + 2.0f * tp.z); tp = F3(0.0f, 0.0f, 0.0f); }
+    if (nb > max_nb) tp = F3(0.0f, 0.0f, 0.0f);                          // logic.js:111-113 (max_nb = 20)
+    if (!b_hit) { contrib = F3(contrib.x + 2.0f * tp.x, contrib.y + 2.0f * tp.y, contrib.z + 2.0f * tp.z); tp = F3(0.0f, 0.0f, 0.0f); }
     if (tp.x == 0.0f && tp.y == 0.0f && tp.z == 0.0f) {                  // logic.js:121-133
         finished = true; code |= 1u; nb = 0; tp = F3(1.0f, 1.0f, 1.0f);
         int sip = ps.samples_in_pixel[i];

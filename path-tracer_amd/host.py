@@ -272,6 +272,28 @@ def init_scene(device):
 
 
 # ------------------------------------------------------------------ scripts/render/path-tracer.js
+MATERIAL_TYPES = {"lambert": capi.PT_MAT_LAMBERT, "emitter": capi.PT_MAT_EMITTER, "mirror": capi.PT_MAT_MIRROR}
+
+
+def render_ext(settings, cls=None):
+    """settings.{maxNb, seed, materials} -> pt_render_ext, or None when none of them is given (the reference has none of
+    these: SURVEY 8f.1).  materials: list of {"type": "lambert"|"emitter"|"mirror", "albedo": [r,g,b], "emission": [r,g,b]}
+    describing material ids 2, 3, ..."""
+    if not any(k in settings for k in ("maxNb", "seed", "materials")):
+        return None
+    ext = (cls or capi.PtRenderExt)()
+    ext.max_nb = int(settings.get("maxNb", 0)); ext.seed = int(settings.get("seed", 0)) & 0xFFFFFFFF
+    mats = settings.get("materials", [])
+    if len(mats) > capi.PT_MAX_EXT_MATERIALS:
+        raise ValueError(f"at most {capi.PT_MAX_EXT_MATERIALS} extension materials")
+    ext.n_materials = len(mats)
+    for k, m in enumerate(mats):
+        ext.materials[k].type = MATERIAL_TYPES[m["type"]]
+        ext.materials[k].albedo[:] = [float(x) for x in m.get("albedo", [0, 0, 0])]
+        ext.materials[k].emission[:] = [float(x) for x in m.get("emission", [0, 0, 0])]
+    return ext
+
+
 class PathTracer:
     FIELDS = {"pixel_index": (np.int32, 1), "num_bounces": (np.int32, 1), "random_seed": (np.float32, 1),
               "path_throughput": (np.float32, 4), "material_throughput_pdf": (np.float32, 4), "path_o": (np.float32, 4),
@@ -296,6 +318,9 @@ class PathTracer:
         self.num_paths = p.num_paths or 1_000_000
         self.width, self.height = p.width, p.height
         self.device.call("pt_render_init", C.byref(p))
+        ext = render_ext(s)
+        if ext is not None:
+            self.device.call("pt_render_set_extensions", C.byref(ext))
 
     def reset(self):
         """Render the same frame again (what calling initPathTracer a second time gives), no reallocation."""

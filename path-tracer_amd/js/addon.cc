@@ -159,6 +159,25 @@ static napi_value RenderInit(napi_env env, napi_callback_info info) {
     if (rc < 0) return throw_pt(env, c, "pt_render_init", rc);
     return nullptr;
 }
+// renderSetExtensions(ctx, maxNb, seed, Float32Array mats|null)              [pt_render_set_extensions]
+// mats: 8 floats per extension material (ids 2, 3, ...): albedo r g b, type (0 Lambert, 1 emitter, 2 mirror), emission r g b, 0
+static napi_value RenderSetExtensions(napi_env env, napi_callback_info info) {
+    napi_value a[4]; if (!get_args(env, info, 4, a)) return nullptr;
+    pt_ctx* c = ctx_of(env, a[0]); if (!c) return nullptr;
+    pt_render_ext e; memset(&e, 0, sizeof e);
+    e.max_nb = (int32_t)i64(env, a[1]); e.seed = (uint32_t)i64(env, a[2]);
+    void* d; size_t nb; if (!ta(env, a[3], &d, &nb)) return nullptr;
+    if (nb % 32 || nb / 32 > PT_MAX_EXT_MATERIALS) { napi_throw_range_error(env, nullptr, "renderSetExtensions: 8 floats per material, at most 14 materials"); return nullptr; }
+    e.n_materials = (int32_t)(nb / 32);
+    const float* f = (const float*)d;
+    for (int k = 0; k < e.n_materials; k++) {
+        for (int j = 0; j < 3; j++) { e.materials[k].albedo[j] = f[8 * k + j]; e.materials[k].emission[j] = f[8 * k + 4 + j]; }
+        e.materials[k].type = (int32_t)f[8 * k + 3];
+    }
+    int rc = pt_render_set_extensions(c, &e);
+    if (rc < 0) return throw_pt(env, c, "pt_render_set_extensions", rc);
+    return nullptr;
+}
 // renderReset(ctx)                                                          [pt_render_reset]
 static napi_value RenderReset(napi_env env, napi_callback_info info) {
     napi_value a[1]; if (!get_args(env, info, 1, a)) return nullptr;
@@ -213,6 +232,7 @@ static napi_value Init(napi_env env, napi_value exports) {
     struct { const char* name; napi_callback fn; } fns[] = {
         {"create", Create}, {"destroy", Destroy}, {"meshUpload", MeshUpload}, {"sceneBuild", SceneBuild}, {"sceneInfo", SceneInfo},
         {"readBuffer", ReadBuffer}, {"traceRays", TraceRays}, {"renderInit", RenderInit}, {"renderReset", RenderReset},
+        {"renderSetExtensions", RenderSetExtensions},
         {"renderStep", RenderStep}, {"renderRun", RenderRun}, {"imageRead", ImageRead}, {"tonemap", Tonemap}};
     for (auto& f : fns) {
         napi_value v; napi_create_function(env, f.name, NAPI_AUTO_LENGTH, f.fn, nullptr, &v);

@@ -3,13 +3,18 @@
 // (registerMesh x k -> instanceMesh x m -> await build() -> initPathTracer -> initDisplay -> loop { await step(); draw() }),
 // no browser.  The reference's demo meshes (cow / bunny / buddha) are not distributed with it, so the demo scene is
 // the floor it does bundle under a lattice of generated boxes standing in for the 100 instanced meshes (main.js:25-33).
-//   node main.js [--width W] [--height H] [--samples S] [--paths N] [--grid G] [--out frame.png] [--json]
+//   node main.js [--width W] [--height H] [--samples S] [--paths N] [--grid G] [--out frame.png] [--json] [--ext]
+// --ext switches the extensions on (not in the reference): box i gets material 1 + i % 4, i.e. the reference's dark grey,
+// an orange Lambert, a mirror and a warm emitter; bounce cut at nb > 8; seed 3.
 "use strict"
 const pt = require("./pt-host.js")
 
 const FLOOR = "v -10.0 -10.0 0.0\nv  10.0 -10.0 0.0\nv  10.0  10.0 0.0\nv -10.0  10.0 0.0\n\nf 1 2 3\nf 1 3 4"
 const BOX = ["v -0.5 -0.5 0", "v 0.5 -0.5 0", "v 0.5 0.5 0", "v -0.5 0.5 0", "v -0.5 -0.5 1.4", "v 0.5 -0.5 1.4", "v 0.5 0.5 1.4", "v -0.5 0.5 1.4",
              "f 1 4 3 2", "f 5 6 7 8", "f 1 2 6 5", "f 3 4 8 7", "f 1 5 8 4", "f 2 3 7 6"].join("\n")
+
+const EXT = { maxNb: 8, seed: 3, materials: [{ type: "lambert", albedo: [0.8, 0.35, 0.05] }, { type: "mirror", albedo: [0.9, 0.9, 0.9] },
+                                            { type: "emitter", emission: [6, 4, 2] }] }
 
 function arg(name, dflt) {
     const i = process.argv.indexOf("--" + name)
@@ -27,7 +32,8 @@ async function main() {
     let lcg = 12345                                  // seeded stand-in for Math.random() (main.js:28) so runs are repeatable
     for (let i = 0; i < grid * grid; i++) {
         lcg = (Math.imul(lcg, 1664525) + 1013904223) >>> 0
-        scene.instanceMesh(box, [(i % grid) * 2, Math.floor(i / grid) * 2, -1.3], [0, 0, lcg / 4294967296 * Math.PI * 2.], [1, 1, 1], 1)
+        scene.instanceMesh(box, [(i % grid) * 2, Math.floor(i / grid) * 2, -1.3], [0, 0, lcg / 4294967296 * Math.PI * 2.], [1, 1, 1],
+                           arg("ext", false) ? 1 + i % 4 : 1)
     }
     scene.instanceMesh(floor, [10, 10, -1.3], [0, 0, 0], [5, 5, 5], 0)
     await scene.build()
@@ -36,7 +42,7 @@ async function main() {
         device, scene,
         image: { width, height },
         camera: { lookAt: [10, 10, 0], position: [15, 15, 5], fov: 60 },     // main.js:42-46
-        settings: { samples, numPaths: +arg("paths", 0) },
+        settings: Object.assign({ samples, numPaths: +arg("paths", 0) }, arg("ext", false) ? EXT : {}),
     })
     const display = pt.initDisplay({ device, canvas: arg("out", null), image: { buffer: tracer.getImageBuffer(), width, height } })
 

@@ -144,6 +144,16 @@ function initPathTracer(params) {
         samples: s.samples, numPaths: s.numPaths || 0, slotBase: s.slotBase || 0,
         ticketBegin: s.ticketBegin || 0, ticketEnd: s.ticketEnd === undefined ? -1 : s.ticketEnd,
     })
+    // extensions the reference does not have (default-off): settings.maxNb, settings.seed, settings.materials =
+    // [{type: "lambert"|"emitter"|"mirror", albedo: [r,g,b], emission: [r,g,b]}, ...] for material ids 2, 3, ...
+    if (s.maxNb !== undefined || s.seed !== undefined || s.materials !== undefined) {
+        const types = { lambert: 0, emitter: 1, mirror: 2 }, mats = s.materials || [], f = new Float32Array(8 * mats.length)
+        mats.forEach((m, k) => {
+            if (!(m.type in types)) throw new Error(`unknown material type ${m.type}`)
+            f.set(m.albedo || [0, 0, 0], 8 * k); f[8 * k + 3] = types[m.type]; f.set(m.emission || [0, 0, 0], 8 * k + 4)
+        })
+        addon().renderSetExtensions(device.ctx, s.maxNb || 0, s.seed || 0, f)
+    }
     async function step() { return addon().renderStep(device.ctx) }                 // path-tracer.js:49-123
     function getImageBuffer() { return { device, width: params.image.width, height: params.image.height } }   // :125-127
     async function run(maxSteps = 0, flags = 0) { return addon().renderRun(device.ctx, maxSteps, flags) }     // main.js:61-72 loop

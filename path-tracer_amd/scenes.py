@@ -62,6 +62,26 @@ def cornell_box(single_mesh=False):
             "instances": [(0, [0, 0, 0], [0, 0, 0], [1, 1, 1], 0), (1, [0, 0, 0], [0, 0, 0], [1, 1, 1], 1)], "camera": cam}
 
 
+def cornell_box_ext():
+    """C2's extension variant (no reference counterpart): red / green side walls, a ceiling light, a mirror
+    tall box and a grey short box.  Material ids 2.. index `materials` (settings.materials of init_path_tracer)."""
+    wv = np.array([[-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0], [-1, -1, 2], [1, -1, 2], [1, 1, 2], [-1, 1, 2]], float)
+    grey = np.asarray(_quad(0, 1, 2, 3) + _quad(4, 7, 6, 5) + _quad(3, 2, 6, 7))     # floor, ceiling, back
+    left, right = np.asarray(_quad(0, 3, 7, 4)), np.asarray(_quad(1, 5, 6, 2))
+    lv = np.array([[-0.35, -0.35, 1.995], [0.35, -0.35, 1.995], [0.35, 0.35, 1.995], [-0.35, 0.35, 1.995]], float)
+    lf = np.asarray(_quad(0, 3, 2, 1))
+    b1v, b1f = _box_faces([-0.65, -0.05, 0.0], [-0.05, 0.55, 1.2], rot_z=0.30)
+    b2v, b2f = _box_faces([0.10, -0.60, 0.0], [0.70, 0.00, 0.6], rot_z=-0.28)
+    meshes = [mesh_from_vertices(wv, grey), mesh_from_vertices(wv, left), mesh_from_vertices(wv, right), mesh_from_vertices(lv, lf),
+              mesh_from_vertices(b1v, b1f), mesh_from_vertices(b2v, b2f)]
+    ident = ([0, 0, 0], [0, 0, 0], [1, 1, 1])
+    inst = [(0, *ident, 0), (1, *ident, 2), (2, *ident, 3), (3, *ident, 4), (4, *ident, 5), (5, *ident, 1)]
+    materials = [{"type": "lambert", "albedo": [0.63, 0.065, 0.05]}, {"type": "lambert", "albedo": [0.14, 0.45, 0.091]},
+                 {"type": "emitter", "emission": [17.0, 12.0, 4.0]}, {"type": "mirror", "albedo": [0.9, 0.9, 0.9]}]
+    return {"meshes": meshes, "instances": inst, "camera": {"position": [0.0, -4.6, 1.0], "lookAt": [0.0, 0.0, 1.0], "fov": 20.0},
+            "materials": materials}
+
+
 def floor_scene():
     """C1: the reference's floor instance and camera (main.js:33,42-46)."""
     return {"meshes": [{"file": FLOOR_OBJ}], "instances": [(0, [10, 10, -1.3], [0, 0, 0], [5, 5, 5], 0)],

@@ -18,6 +18,15 @@ class OrcRenderParams(C.Structure):
                 ("ticket_begin", C.c_int64), ("ticket_end", C.c_int64)]
 
 
+class OrcMaterial(C.Structure):
+    _fields_ = [("albedo", C.c_float * 3), ("type", C.c_int32), ("emission", C.c_float * 3), ("pad", C.c_int32)]
+
+
+class OrcRenderExt(C.Structure):
+    _fields_ = [("max_nb", C.c_int32), ("seed", C.c_uint32), ("n_materials", C.c_int32), ("pad", C.c_int32),
+                ("materials", OrcMaterial * 14)]
+
+
 class OrcStepStats(C.Structure):
     _fields_ = [("n_camera", C.c_int64), ("n_material", C.c_int64), ("n_rays", C.c_int64), ("n_live", C.c_int64)]
 
@@ -50,6 +59,7 @@ def lib():
             "orc_trace_max_depth": (i32, []),
             "orc_brute_force": (None, [vp, vp, vp, i64, vp, vp, vp, i32]),
             "orc_render_create": (vp, [vp, C.POINTER(OrcRenderParams)]), "orc_render_destroy": (None, [vp]),
+            "orc_render_set_extensions": (None, [vp, C.POINTER(OrcRenderExt)]),
             "orc_render_step": (None, [vp, C.POINTER(OrcStepStats), i32]),
             "orc_render_phase": (None, [vp, i32, C.POINTER(OrcStepStats), i32]),
             "orc_render_run": (i64, [vp, i64, C.POINTER(i64), C.POINTER(i64), i32]),
@@ -151,7 +161,7 @@ FIELDS = {"pixel_index": (np.int32, 1), "num_bounces": (np.int32, 1), "random_se
 
 
 class OrcRender:
-    def __init__(self, scene, width, height, camera, spp, num_paths, slot_base=0, ticket_begin=0, ticket_end=-1):
+    def __init__(self, scene, width, height, camera, spp, num_paths, slot_base=0, ticket_begin=0, ticket_end=-1, ext=None):
         self.scene = scene
         p = OrcRenderParams()
         p.width, p.height, p.spp, p.num_paths = width, height, spp, num_paths
@@ -160,6 +170,10 @@ class OrcRender:
         p.slot_base, p.ticket_begin, p.ticket_end = slot_base, ticket_begin, ticket_end
         self.p = p
         self.h = lib().orc_render_create(scene.h, C.byref(p))
+        if ext:                                       # same settings dict the product host takes (host.render_ext)
+            e = host.render_ext(ext, OrcRenderExt)
+            if e is not None:
+                lib().orc_render_set_extensions(self.h, C.byref(e))
 
     def __del__(self):
         try:

@@ -274,6 +274,55 @@ def test_wave_log_hook(pta, device, built):
     assert pt.read_image()[..., 3].sum() == 96 * 54 * 16 and img_before[..., 3].sum() <= 96 * 54 * 16
 
 
+def test_extensions_bit_exact_against_the_oracle(pta, orc, device):
+    """SURVEY 8f.1 extensions (rgb Lambert, emitter, mirror, max_nb, seed): the oracle defines the rules, the kernels
+    reproduce them -- whole path state after every step, then the finished frame."""
+    desc = pta.scenes.cornell_box_ext()
+    s = pta.scenes.populate(pta.init_scene(device), desc); s.build()
+    o = orc.OrcScene(desc)
+    ext = {"maxNb": 8, "seed": 7, "materials": desc["materials"]}
+    w, h, spp, paths = 96, 54, 16, 6000
+    pt = pta.init_path_tracer({"device": device, "scene": s, "image": {"width": w, "height": h}, "camera": desc["camera"],
+                               "settings": dict(samples=spp, numPaths=paths, **ext)})
+    orr = orc.OrcRender(o, w, h, desc["camera"], spp, paths, ext=ext)
+    for step in range(25):
+        gs = pt.step(); cs = orr.step_like_device()
+        assert (gs.n_camera, gs.n_material) == (cs.n_camera, cs.n_material), step
+        assert_state_equal(pt, orr, step)
+    assert pt.field("num_bounces").max() <= 10
+    pt.run()
+    while orr.step_like_device().n_rays:
+        pass
+    img_g, img_c = pt.read_image(), orr.image()
+    np.testing.assert_array_equal(img_g[..., 3], img_c[..., 3])
+    np.testing.assert_allclose(img_g[..., :3], img_c[..., :3], rtol=1e-5, atol=1e-5)
+    assert img_g[..., 0].sum() > img_g[..., 2].sum() > 0       # warm light, red wall
+
+
+def test_extensions_closed_forms_and_reset(pta, device):
+    """emitter: first hit ends the path with exactly the emission; mirror under the sky: exactly 2 * albedo; extensions
+    survive reset(); a new init_path_tracer without them is the reference again."""
+    desc = {"meshes": [{"file": pta.scenes.FLOOR_OBJ}], "instances": [(0, [0, 0, 0], [0, 0, 0], [5, 5, 5], 2)],
+            "camera": {"position": [0, 0, 8], "lookAt": [0, 0.001, 0], "fov": 20}}
+    s = pta.scenes.populate(pta.init_scene(device), desc); s.build()
+    base = {"device": device, "scene": s, "image": {"width": 16, "height": 16}, "camera": desc["camera"]}
+    for mats, expect in (([{"type": "emitter", "emission": [3.0, 1.5, 0.25]}], [3.0, 1.5, 0.25]),
+                         ([{"type": "mirror", "albedo": [0.5, 0.25, 1.0]}], [1.0, 0.5, 2.0])):
+        pt = pta.init_path_tracer(dict(base, settings={"samples": 8, "numPaths": 300, "materials": mats}))
+        for again in range(2):
+            pt.run()
+            img = pt.read_image()
+            np.testing.assert_array_equal(img[..., :3] / img[..., 3:4], np.broadcast_to(np.float32(expect), (16, 16, 3)))
+            pt.reset()
+    pt = pta.init_path_tracer(dict(base, settings={"samples": 8, "numPaths": 300}))      # id 2 unknown again: black
+    pt.run()
+    assert np.all(pt.read_image()[..., :3] == 0)
+    with pytest.raises(pta.capi.PtError, match="started"):
+        import ctypes as C
+        pt.reset(); pt.step()
+        device.call("pt_render_set_extensions", C.byref(pta.capi.PtRenderExt()))
+
+
 def test_error_behaviour(pta, device):
     """Reference: console.warn + undefined (scene.js:149,525); here: negative status + message."""
     dev2 = pta.request_device(0)

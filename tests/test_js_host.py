@@ -46,13 +46,20 @@ BOX = "\n".join(["v -0.5 -0.5 0", "v 0.5 -0.5 0", "v 0.5 0.5 0", "v -0.5 0.5 0",
                  "v -0.5 0.5 1.4", "f 1 4 3 2", "f 5 6 7 8", "f 1 2 6 5", "f 3 4 8 7", "f 1 5 8 4", "f 2 3 7 6"])
 
 
+EXT = {"maxNb": 8, "seed": 3, "materials": [{"type": "lambert", "albedo": [0.8, 0.35, 0.05]}, {"type": "mirror", "albedo": [0.9, 0.9, 0.9]},
+                                            {"type": "emitter", "emission": [6, 4, 2]}]}
+
+
 @needs_node
 @pytest.mark.gpu
-def test_node_render_equals_python_host_render(pta, device):
-    """main.js (JS host -> N-API -> C ABI) and the Python host drive the same library: identical frames."""
+@pytest.mark.parametrize("ext", [False, True])
+def test_node_render_equals_python_host_render(pta, device, ext):
+    """main.js (JS host -> N-API -> C ABI) and the Python host drive the same library: identical frames, with the
+    reference's rules and with the extensions (materials, bounce cut, seed) switched on."""
     w, h, spp, paths, grid = 64, 48, 8, 3000, 3
     r = subprocess.run([NODE, "main.js", "--width", str(w), "--height", str(h), "--samples", str(spp), "--paths", str(paths),
-                        "--grid", str(grid), "--json", "--out", "/tmp/node_frame.png"], cwd=JS, capture_output=True, text=True, timeout=240)
+                        "--grid", str(grid), "--json", "--out", "/tmp/node_frame.png"] + (["--ext"] if ext else []),
+                       cwd=JS, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout + r.stderr
     rep = json.loads(r.stdout.strip().splitlines()[-1])
     scene = pta.init_scene(device)
@@ -60,11 +67,12 @@ def test_node_render_equals_python_host_render(pta, device):
     lcg = 12345
     for i in range(grid * grid):
         lcg = (lcg * 1664525 + 1013904223) & 0xFFFFFFFF
-        scene.instance_mesh(box, [(i % grid) * 2, (i // grid) * 2, -1.3], [0, 0, lcg / 4294967296 * math.pi * 2.0], [1, 1, 1], 1)
+        scene.instance_mesh(box, [(i % grid) * 2, (i // grid) * 2, -1.3], [0, 0, lcg / 4294967296 * math.pi * 2.0], [1, 1, 1], 1 + i % 4 if ext else 1)
     scene.instance_mesh(floor, [10, 10, -1.3], [0, 0, 0], [5, 5, 5], 0)
     scene.build()
     pt = pta.init_path_tracer({"device": device, "scene": scene, "image": {"width": w, "height": h},
-                               "camera": {"lookAt": [10, 10, 0], "position": [15, 15, 5], "fov": 60}, "settings": {"samples": spp, "numPaths": paths}})
+                               "camera": {"lookAt": [10, 10, 0], "position": [15, 15, 5], "fov": 60},
+                               "settings": dict({"samples": spp, "numPaths": paths}, **(EXT if ext else {}))})
     rs = pt.run()
     img = pt.read_image()
     assert rep["steps"] == rs.steps and rep["rays"] == rs.total_rays

@@ -278,3 +278,56 @@ def test_device_phase_order_is_the_reference_order(orc):
     np.testing.assert_array_equal(a.image().view(np.uint32), b.image().view(np.uint32))
     for f in orc.FIELDS:
         np.testing.assert_array_equal(a.field(f).view(np.uint32), b.field(f).view(np.uint32))
+
+
+# ---- extensions: rules defined by the oracle, nothing in the reference to pin them -- closed forms instead
+def _plane_scene(pta, material):
+    """the reference's floor quad, 100 x 100 units, seen from straight above"""
+    return {"meshes": [{"file": pta.scenes.FLOOR_OBJ}], "instances": [(0, [0, 0, 0], [0, 0, 0], [5, 5, 5], material)],
+            "camera": {"position": [0, 0, 8], "lookAt": [0, 0.001, 0], "fov": 20}}
+
+
+def test_extensions_default_off(orc, pta):
+    desc = pta.scenes.cornell_box()
+    s = orc.OrcScene(desc)
+    a = orc.OrcRender(s, 32, 18, desc["camera"], 16, 700)
+    b = orc.OrcRender(s, 32, 18, desc["camera"], 16, 700, ext={"maxNb": 0, "seed": 0, "materials": []})
+    a.run(); b.run()
+    np.testing.assert_array_equal(a.image().view(np.uint32), b.image().view(np.uint32))
+    for f in orc.FIELDS:
+        np.testing.assert_array_equal(a.field(f).view(np.uint32), b.field(f).view(np.uint32))
+
+
+def test_extension_emitter_and_mirror_closed_forms(orc, pta):
+    e = [3.0, 1.5, 0.25]
+    for mats, expect in (([{"type": "emitter", "emission": e}], e),                         # first hit ends the path: exactly e
+                         ([{"type": "mirror", "albedo": [0.5, 0.25, 1.0]}], [1.0, 0.5, 2.0])):   # one bounce into the sky (2): 2 * albedo
+        desc = _plane_scene(pta, 2)
+        r = orc.OrcRender(orc.OrcScene(desc), 16, 16, desc["camera"], 8, 300, ext={"materials": mats})
+        r.run()
+        img = r.image()
+        assert np.all(img[..., 3] == 8)
+        np.testing.assert_array_equal(img[..., :3] / img[..., 3:4], np.broadcast_to(np.float32(expect), (16, 16, 3)))
+    # a material id without an entry keeps the reference's unknown-id rule: zero BRDF, the path contributes nothing
+    desc = _plane_scene(pta, 5)
+    r = orc.OrcRender(orc.OrcScene(desc), 8, 8, desc["camera"], 8, 100, ext={"materials": [{"type": "emitter", "emission": e}]})
+    r.run()
+    assert np.all(r.image()[..., :3] == 0) and np.all(r.image()[..., 3] == 8)
+
+
+def test_extension_max_nb_and_seed(orc, pta):
+    desc = pta.scenes.cornell_box()
+    s = orc.OrcScene(desc)
+    def bounces(ext):
+        r = orc.OrcRender(s, 32, 18, desc["camera"], 16, 700, ext=ext)
+        seen = set()
+        for _ in range(40):
+            r.step(); seen.update(np.unique(r.field("num_bounces")).tolist())
+        return r, seen
+    r0, seen0 = bounces(None)
+    r1, seen1 = bounces({"maxNb": 4})
+    assert max(seen0) > 6 and max(seen1) <= 6          # nb advances by 2 per bounce; a path is cut once nb > max_nb
+    r2, _ = bounces({"seed": 7}); r3, _ = bounces({"seed": 7}); r4, _ = bounces({"seed": 8})
+    np.testing.assert_array_equal(r2.field("random_seed"), r3.field("random_seed"))
+    assert not np.array_equal(r2.field("random_seed"), r0.field("random_seed"))
+    assert not np.array_equal(r2.field("random_seed"), r4.field("random_seed"))
