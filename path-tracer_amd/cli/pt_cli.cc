@@ -1,0 +1,180 @@
+// pt_cli.cc -- Node-free host for libpt_amd.so (SURVEY 8b "caller", 8f.3): the reference's main.js call sequence
+// (registerMesh x k -> instanceMesh x m -> build -> initPathTracer -> loop { step } -> display) in C++ over the C ABI.
+//
+//   pt_cli [--obj FILE]... [--instance MESH,px,py,pz,rx,ry,rz,sx,sy,sz,MATERIAL]... [--camera px,py,pz,lx,ly,lz,fov]
+//          [--width W] [--height H] [--samples S] [--paths N] [--device D] [--progress K] [--out frame.png|frame.ppm] [--json]
+//   pt_cli --dump-host FILE px,py,pz,rx,ry,rz,sx,sy,sz      host-side results only (no GPU): parse + matrices + world box as JSON
+//
+// Without --obj the scene is the reference's bundled floor with its main.js:33 instance and main.js:42-46 camera.
+// --progress K writes the frame every K steps (the reference redraws every animation frame, main.js:61-72).
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/pt_amd.h"
+#include "pt_host.hpp"
+
+using namespace pt_host;
+
+static const char* FLOOR_OBJ = "v -10.0 -10.0 0.0\nv  10.0 -10.0 0.0\nv  10.0  10.0 0.0\nv -10.0  10.0 0.0\n\nf 1 2 3\nf 1 3 4";
+
+static std::vector<double> csv(const std::string& s) {
+    std::vector<double> v; std::stringstream ss(s); std::string t;
+    while (std::getline(ss, t, ',')) v.push_back(std::strtod(t.c_str(), nullptr));
+    return v;
+}
+static bool read_file(const std::string& path, std::string& out) {
+    std::ifstream f(path, std::ios::binary); if (!f) return false;
+    std::stringstream ss; ss << f.rdbuf(); out = ss.str(); return true;
+}
+static void json_arr(const double* v, int n) {      // NaN -> null, +-inf -> (-)Infinity (what Python's json reads back)
+    printf("[");
+    for (int i = 0; i < n; i++) {
+        const char* sep = i ? ", " : "";
+        if (v[i] != v[i]) printf("%snull", sep);
+        else if (std::isinf(v[i])) printf("%s%sInfinity", sep, v[i] < 0 ? "-" : "");
+        else printf("%s%.17g", sep, v[i]);
+    }
+    printf("]");
+}
+
+// ---- PNG without zlib: stored deflate blocks ----------------------------------------------------------------------------
+static uint32_t crc_table[256];
+static void crc_init() { for (uint32_t n = 0; n < 256; n++) { uint32_t c = n; for (int k = 0; k < 8; k++) c = (c & 1) ? 0xedb88320u ^ (c >> 1) : c >> 1; crc_table[n] = c; } }
+static uint32_t crc32(const uint8_t* p, size_t n, uint32_t c = 0xffffffffu) { for (size_t i = 0; i < n; i++) c = crc_table[(c ^ p[i]) & 0xff] ^ (c >> 8); return c; }
+static void be32(std::vector<uint8_t>& v, uint32_t x) { for (int s = 24; s >= 0; s -= 8) v.push_back((uint8_t)(x >> s)); }
+static void chunk(std::vector<uint8_t>& out, const char* type, const std::vector<uint8_t>& data) {
+    be32(out, (uint32_t)data.size());
+    std::vector<uint8_t> td(type, type + 4); td.insert(td.end(), data.begin(), data.end());
+    out.insert(out.end(), td.begin(), td.end());
+    be32(out, crc32(td.data(), td.size()) ^ 0xffffffffu);
+}
+static bool write_image(const std::string& path, const uint8_t* rgba, int w, int h) {
+    FILE* f = fopen(path.c_str(), "wb"); if (!f) return false;
+    if (path.size() > 4 && path.substr(path.size() - 4) == ".ppm") {
+        fprintf(f, "P6\n%d %d\n255\n", w, h);
+        for (int i = 0; i < w * h; i++) fwrite(rgba + 4 * i, 1, 3, f);
+    } else {
+        crc_init();
+        std::vector<uint8_t> raw; raw.reserve((size_t)h * (4 * w + 1));
+        for (int y = 0; y < h; y++) { raw.push_back(0); raw.insert(raw.end(), rgba + (size_t)4 * w * y, rgba + (size_t)4 * w * (y + 1)); }
+        std::vector<uint8_t> z = {0x78, 0x01};
+        uint32_t a = 1, b = 0;
+        for (uint8_t c : raw) { a = (a + c) % 65521; b = (b + a) % 65521; }
+        for (size_t off = 0; off < raw.size() || off == 0; off += 65535) {
+            size_t n = std::min<size_t>(65535, raw.size() - off);
+            z.push_back(off + n >= raw.size() ? 1 : 0);
+            z.push_back((uint8_t)(n & 0xff)); z.push_back((uint8_t)(n >> 8)); z.push_back((uint8_t)(~n & 0xff)); z.push_back((uint8_t)((~n >> 8) & 0xff));
+            z.insert(z.end(), raw.begin() + off, raw.begin() + off + n);
+            if (raw.empty()) break;
+        }
+        be32(z, (b << 16) | a);
+        std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a}, ihdr;
+        be32(ihdr, (uint32_t)w); be32(ihdr, (uint32_t)h); ihdr.insert(ihdr.end(), {8, 6, 0, 0, 0});
+        chunk(out, "IHDR", ihdr); chunk(out, "IDAT", z); chunk(out, "IEND", {});
+        fwrite(out.data(), 1, out.size(), f);
+    }
+    fclose(f);
+    return true;
+}
+
+static int dump_host(const std::string& file, const std::string& trs) {
+    std::string text; if (!read_file(file, text)) { fprintf(stderr, "cannot read %s\n", file.c_str()); return 2; }
+    ParsedObj p = parse_obj(text);
+    std::vector<double> t = csv(trs); t.resize(9, 0.0);
+    TransformMatrices m = compute_transform_matrices(&t[0], &t[3], &t[6]);
+    Bounds wb = get_transformed_bounding_box(m.l2w, p.bounds);
+    printf("{\"numTriangles\": %lld, \"triangleArray\": ", (long long)p.num_triangles()); json_arr(p.tris.data(), (int)p.tris.size());
+    printf(", \"bounds\": {\"min\": "); json_arr(p.bounds.mn, 3); printf(", \"max\": "); json_arr(p.bounds.mx, 3);
+    printf("}, \"localToWorld\": "); json_arr(m.l2w.m, 16); printf(", \"worldToLocal\": "); json_arr(m.w2l.m, 16);
+    printf(", \"worldBox\": {\"min\": "); json_arr(wb.mn, 3); printf(", \"max\": "); json_arr(wb.mx, 3); printf("}}\n");
+    return 0;
+}
+
+#define CHECK(call) do { int rc_ = (call); if (rc_ < 0) { fprintf(stderr, "%s failed (%d): %s\n", #call, rc_, pt_last_error(ctx)); if (ctx) pt_destroy(ctx); return 1; } } while (0)
+
+int main(int argc, char** argv) {
+    std::vector<std::string> objs, insts; std::string cam, out; bool json = false;
+    int width = 512, height = 512, samples = 16, paths = 0, device = 0, progress = 0;
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        auto next = [&]() -> std::string { return i + 1 < argc ? argv[++i] : ""; };
+        if (a == "--dump-host") { std::string f = next(); return dump_host(f, next()); }
+        else if (a == "--obj") objs.push_back(next());
+        else if (a == "--instance") insts.push_back(next());
+        else if (a == "--camera") cam = next();
+        else if (a == "--width") width = atoi(next().c_str());
+        else if (a == "--height") height = atoi(next().c_str());
+        else if (a == "--samples") samples = atoi(next().c_str());
+        else if (a == "--paths") paths = atoi(next().c_str());
+        else if (a == "--device") device = atoi(next().c_str());
+        else if (a == "--progress") progress = atoi(next().c_str());
+        else if (a == "--out") out = next();
+        else if (a == "--json") json = true;
+        else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
+    }
+    std::vector<std::string> texts;
+    if (objs.empty()) { texts.push_back(FLOOR_OBJ); if (insts.empty()) insts.push_back("0,10,10,-1.3,0,0,0,5,5,5,0"); }   // main.js:33
+    for (const std::string& f : objs) { std::string t; if (!read_file(f, t)) { fprintf(stderr, "cannot read %s\n", f.c_str()); return 2; } texts.push_back(t); }
+    if (insts.empty()) for (size_t m = 0; m < texts.size(); m++) insts.push_back(std::to_string(m) + ",0,0,0,0,0,0,1,1,1,0");
+    std::vector<double> c = cam.empty() ? std::vector<double>{15, 15, 5, 10, 10, 0, 60} : csv(cam);                       // main.js:42-46
+    c.resize(7, 60.0);
+
+    pt_ctx* ctx = nullptr;
+    CHECK(pt_create(device, &ctx));
+    std::vector<int> handles; std::vector<Bounds> bounds;
+    for (const std::string& t : texts) {                                          // registerMesh (scene.js:518)
+        ParsedObj p = parse_obj(t);
+        std::vector<float> tris(p.tris.begin(), p.tris.end());                    // builders.js:164 Float32Array.set
+        float b6[6]; for (int k = 0; k < 3; k++) { b6[k] = (float)p.bounds.mn[k]; b6[3 + k] = (float)p.bounds.mx[k]; }
+        int h = pt_mesh_upload(ctx, tris.data(), p.num_triangles(), b6);
+        if (h < 0) { fprintf(stderr, "pt_mesh_upload failed (%d): %s\n", h, pt_last_error(ctx)); pt_destroy(ctx); return 1; }
+        handles.push_back(h); bounds.push_back(p.bounds);
+    }
+    std::vector<pt_instance> inst;
+    for (const std::string& s : insts) {                                          // instanceMesh (scene.js:523-529) + scene.js:35-46
+        std::vector<double> v = csv(s); v.resize(11, 0.0);
+        int mesh = (int)v[0];
+        if (mesh < 0 || mesh >= (int)handles.size()) { fprintf(stderr, "warning: instance of unknown mesh %d skipped\n", mesh); continue; }   // scene.js:525
+        TransformMatrices m = compute_transform_matrices(&v[1], &v[4], &v[7]);
+        Bounds wb = get_transformed_bounding_box(m.l2w, bounds[mesh]);
+        pt_instance pi; memset(&pi, 0, sizeof pi);
+        for (int k = 0; k < 16; k++) { pi.l2w[k] = (float)m.l2w.m[k]; pi.w2l[k] = (float)m.w2l.m[k]; }
+        for (int k = 0; k < 3; k++) { pi.aabb_min[k] = (float)wb.mn[k]; pi.aabb_max[k] = (float)wb.mx[k]; }
+        pi.mesh = handles[mesh]; pi.material = (int)v[10];
+        inst.push_back(pi);
+    }
+    CHECK(pt_scene_build(ctx, inst.data(), (int)inst.size()));
+    pt_scene_info si; CHECK(pt_scene_get_info(ctx, &si));
+
+    pt_render_params rp; memset(&rp, 0, sizeof rp);
+    rp.width = width; rp.height = height; rp.spp = samples; rp.num_paths = paths; rp.ticket_end = -1; rp.fov_deg = (float)c[6];
+    for (int k = 0; k < 3; k++) { rp.cam_pos[k] = (float)c[k]; rp.cam_look_at[k] = (float)c[3 + k]; }
+    CHECK(pt_render_init(ctx, &rp));
+
+    std::vector<uint8_t> rgba((size_t)width * height * 4);
+    long long steps = 0, rays = 0; int frames = 0;
+    for (;;) {                                                                    // main.js:61-72, stopping on empty queues
+        pt_step_stats st; CHECK(pt_render_step(ctx, &st));
+        steps++; rays += st.n_rays;
+        bool done = st.n_camera + st.n_material == 0;
+        if (!out.empty() && (done || (progress > 0 && steps % progress == 0))) {
+            CHECK(pt_tonemap_rgba8(ctx, nullptr, 0, 0, rgba.data()));
+            if (!write_image(out, rgba.data(), width, height)) { fprintf(stderr, "cannot write %s\n", out.c_str()); pt_destroy(ctx); return 2; }
+            frames++;
+        }
+        if (done) break;
+    }
+    std::vector<float> img((size_t)width * height * 4);
+    CHECK(pt_image_read(ctx, img.data(), (int64_t)img.size()));
+    double wsum = 0, rsum = 0; for (size_t i = 0; i < (size_t)width * height; i++) { wsum += img[4 * i + 3]; rsum += img[4 * i]; }
+    if (json) printf("{\"width\": %d, \"height\": %d, \"samples\": %d, \"steps\": %lld, \"rays\": %lld, \"sampleCount\": %.17g, \"radianceSum\": %.17g, "
+                     "\"nTris\": %lld, \"nObjects\": %d, \"frames\": %d}\n", width, height, samples, steps, rays, wsum, rsum, (long long)si.n_tris, si.n_objects, frames);
+    else printf("%dx%d, %d spp: %lld steps, %lld rays, %lld triangles in %d instances%s%s\n", width, height, samples, steps, rays,
+                (long long)si.n_tris, si.n_objects, out.empty() ? "" : " -> ", out.c_str());
+    pt_destroy(ctx);
+    return 0;
+}
