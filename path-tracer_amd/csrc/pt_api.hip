@@ -606,8 +606,9 @@ int pt_tonemap_rgba8(pt_ctx* c, const void* image_dev, int32_t width, int32_t he
     if (!image_dev) {
         if (!c->render_ready) return fail(c, PT_ERR_STATE, "pt_tonemap_rgba8: no image");
         image_dev = c->d_image; width = c->rc.width; height = c->rc.height;
-        ptk_flush_tickets(c->ps, c->rc.num_paths, c->d_image, c->stream);
     }
+    if (c->render_ready && image_dev == c->d_image)      // a draw in the middle of a render shows every finished sample
+        ptk_flush_tickets(c->ps, c->rc.num_paths, c->d_image, c->stream);
     if (width < 1 || height < 1) return fail(c, PT_ERR_ARG, "pt_tonemap_rgba8: bad size");
     int64_t n = (int64_t)width * height; uint32_t* d_out = nullptr; int r;
     if ((r = dalloc(c, &d_out, (size_t)n, false))) return r;

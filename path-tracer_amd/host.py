@@ -393,6 +393,59 @@ def init_display(params):
     return Display(params)
 
 
+class DebugView:
+    """initDebug-style visualiser of the traversal (debug/rt-debug.js:69-170): one primary ray per pixel
+    through the extend kernel (pt_trace_rays), coloured by the world-space normal of the closest hit (mode "normal",
+    rt-debug.js:150-156) or by the hit indices (mode "index", the commented line :157); a miss is black.  The camera is
+    rt-debug.js's: pixel corner, no jitter, sin(fov/2) with fov 80 unless given."""
+
+    def __init__(self, params):
+        self.device, self.scene = params["device"], params["scene"]
+        self.image, self.canvas = params["image"], params.get("canvas")
+        self.camera = params["camera"]
+
+    def rays(self):
+        w, h = int(self.image["width"]), int(self.image["height"])
+        f32 = np.float32
+        pos, look = np.asarray(self.camera["position"], f32), np.asarray(self.camera["lookAt"], f32)
+        sinfov = f32(math.sin(0.5 * float(self.camera.get("fov", 80.0)) * math.pi / 180.0))
+        fwd = look - pos; fwd = fwd / np.sqrt((fwd * fwd).sum(dtype=f32))
+        right = np.asarray([fwd[1], -fwd[0], 0.0], f32); right = right / np.sqrt((right * right).sum(dtype=f32))
+        up = np.cross(right, fwd).astype(f32)
+        x, y = np.meshgrid(np.arange(w, dtype=f32), np.arange(h, dtype=f32))
+        sx = x / f32(w) * f32(2) - f32(1); sy = -(y / f32(h) * f32(2) - f32(1))
+        local = np.stack([f32(w / h) * sx * sinfov, np.ones_like(sx), sy * sinfov], -1)
+        local = local / np.sqrt((local * local).sum(-1, keepdims=True, dtype=f32))
+        d = local[..., 0:1] * right + local[..., 1:2] * fwd + local[..., 2:3] * up
+        o = np.broadcast_to(pos, d.shape)
+        return np.ascontiguousarray(o.reshape(-1, 3), f32), np.ascontiguousarray(d.reshape(-1, 3), f32)
+
+    def draw(self, mode="normal"):
+        w, h = int(self.image["width"]), int(self.image["height"])
+        o, d = self.rays()
+        hit_obj, hit_tri, hit_dist = self.scene.trace_rays(o, d)
+        hit = (hit_obj >= 0) & (hit_dist <= 1e5)
+        col = np.zeros((w * h, 3), np.float32)
+        if mode == "index":
+            col[hit, 0] = hit_obj[hit] / np.float32(20.0); col[hit, 1] = hit_tri[hit] / np.float32(5000.0)
+        else:
+            tris = self.scene.blas_tris()[hit_tri[hit]].reshape(-1, 3, 4)[..., :3]
+            ln = np.cross(tris[:, 1] - tris[:, 0], tris[:, 2] - tris[:, 0])
+            ln /= np.linalg.norm(ln, axis=1, keepdims=True)
+            l2w = self.scene.objects_buffer().view(np.float32).reshape(-1, 32)[hit_obj[hit], :12].reshape(-1, 3, 4)[..., :3]
+            n = np.einsum("nij,nj->ni", l2w, ln)
+            col[hit] = n / np.linalg.norm(n, axis=1, keepdims=True)
+        out = np.full((h, w, 4), 255, np.uint8)
+        out[..., :3] = (np.clip(col, 0.0, 1.0) * 255.0 + 0.5).astype(np.uint8).reshape(h, w, 3)
+        if self.canvas:
+            write_image(self.canvas, out)
+        return out
+
+
+def init_debug_view(params):
+    return DebugView(params)
+
+
 def write_image(path, rgba8):
     """PNG (zlib, no dependencies) or binary PPM by extension."""
     import struct

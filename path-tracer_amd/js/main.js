@@ -3,7 +3,8 @@
 // (registerMesh x k -> instanceMesh x m -> await build() -> initPathTracer -> initDisplay -> loop { await step(); draw() }),
 // no browser.  The reference's demo meshes (cow / bunny / buddha) are not distributed with it, so the demo scene is
 // the floor it does bundle under a lattice of generated boxes standing in for the 100 instanced meshes (main.js:25-33).
-//   node main.js [--width W] [--height H] [--samples S] [--paths N] [--grid G] [--out frame.png] [--json] [--ext]
+//   node main.js [--width W] [--height H] [--samples S] [--paths N] [--grid G] [--out frame.png] [--progress K] [--json] [--ext]
+// --progress K redraws (rewrites the PNG) every K steps, the headless form of the reference's draw-every-frame loop.
 // --ext switches the extensions on (not in the reference): box i gets material 1 + i % 4, i.e. the reference's dark grey,
 // an orange Lambert, a mirror and a warm emitter; bounce cut at nb > 8; seed 3.
 "use strict"
@@ -47,11 +48,12 @@ async function main() {
     const display = pt.initDisplay({ device, canvas: arg("out", null), image: { buffer: tracer.getImageBuffer(), width, height } })
 
     // the reference's frame loop never learns that the render finished (main.js:61-72); headless, it stops on empty queues
-    let steps = 0, rays = 0
+    let steps = 0, rays = 0, frames = 0
     const t1 = Date.now()
     for (;;) {
         const st = await tracer.step()
         steps++; rays += st.rays
+        if (+arg("progress", 0) > 0 && steps % +arg("progress", 0) === 0) { display.draw(); frames++ }     // main.js:69
         if (st.camera + st.material === 0) break
     }
     const t2 = Date.now()
@@ -59,7 +61,7 @@ async function main() {
     const img = tracer.readImage()
     let wsum = 0, rsum = 0
     for (let i = 0; i < width * height; i++) { wsum += img[4 * i + 3]; rsum += img[4 * i] }
-    const report = { width, height, samples, steps, rays, buildMs: t1 - t0, renderMs: t2 - t1, sampleCount: wsum, radianceSum: rsum,
+    const report = { width, height, samples, steps, rays, frames: frames + 1, buildMs: t1 - t0, renderMs: t2 - t1, sampleCount: wsum, radianceSum: rsum,
                      firstPixel: Array.from(rgba.slice(0, 4)), info: scene.kernels.getSceneBindGroupInfo() }
     console.log(arg("json", false) ? JSON.stringify(report) : report)
     device.destroy()

@@ -177,6 +177,48 @@ function initDisplay(params) {
     return { draw }
 }
 
+// ---- debug view (debug/rt-debug.js:69-170; SURVEY 8f.2) ----------------------------------------------------------------
+// One primary ray per pixel through the extend kernel, coloured by the world normal of the closest hit ("normal") or by the
+// hit indices ("index", the commented line rt-debug.js:157); a miss is black.  rt-debug.js's camera: pixel corner, no
+// jitter, sin(fov / 2), fov 80 unless given.
+function initDebugView(params) {
+    const { width: w, height: h } = params.image, cam = params.camera, f = Math.fround
+    const sub = (a, b) => a.map((x, i) => f(x - b[i])), norm = v => { const l = f(Math.sqrt(f(f(f(v[0] * v[0]) + f(v[1] * v[1])) + f(v[2] * v[2])))); return v.map(x => f(x / l)) }
+    const cross = (a, b) => [f(f(a[1] * b[2]) - f(a[2] * b[1])), f(f(a[2] * b[0]) - f(a[0] * b[2])), f(f(a[0] * b[1]) - f(a[1] * b[0]))]
+    function draw(mode = "normal") {
+        const pos = cam.position.map(f), fwd = norm(sub(cam.lookAt.map(f), pos)), right = norm([fwd[1], -fwd[0], 0]), up = cross(right, fwd)
+        const sinfov = f(Math.sin(0.5 * (cam.fov === undefined ? 80 : cam.fov) * Math.PI / 180)), aspect = f(w / h)
+        const o = new Float32Array(w * h * 3), d = new Float32Array(w * h * 3)
+        for (let y = 0; y < h; y++) for (let x = 0; x < w; x++) {
+            const sx = f(f(f(x / w) * 2) - 1), sy = -f(f(f(y / h) * 2) - 1)
+            const l = norm([f(f(aspect * sx) * sinfov), 1, f(sy * sinfov)]), i = 3 * (y * w + x)
+            for (let k = 0; k < 3; k++) { o[i + k] = pos[k]; d[i + k] = f(f(f(l[0] * right[k]) + f(l[1] * fwd[k])) + f(l[2] * up[k])) }
+        }
+        const hitObj = new Int32Array(w * h), hitTri = new Int32Array(w * h), hitDist = new Float32Array(w * h)
+        addon().traceRays(params.device.ctx, o, d, hitObj, hitTri, hitDist)
+        const info = params.scene.kernels.getSceneBindGroupInfo()
+        const tris = new Float32Array(12 * info.nTris), objs = new Float32Array(32 * info.nObjects)
+        params.scene.kernels.readBuffer("blasTris", tris); params.scene.kernels.readBuffer("objects", objs)
+        const rgba = new Uint8Array(w * h * 4)
+        for (let p = 0; p < w * h; p++) {
+            let col = [0, 0, 0]
+            if (hitObj[p] >= 0 && hitDist[p] <= 1e5) {
+                if (mode === "index") col = [hitObj[p] / 20, hitTri[p] / 5000, 0]
+                else {
+                    const t = 12 * hitTri[p], v = k => [tris[t + 4 * k], tris[t + 4 * k + 1], tris[t + 4 * k + 2]]
+                    const ln = norm(cross(sub(v(1), v(0)), sub(v(2), v(0)))), m = 32 * hitObj[p]
+                    col = norm([0, 1, 2].map(r => objs[m + 4 * r] * ln[0] + objs[m + 4 * r + 1] * ln[1] + objs[m + 4 * r + 2] * ln[2]))
+                }
+            }
+            for (let k = 0; k < 3; k++) rgba[4 * p + k] = Math.floor(Math.min(Math.max(col[k], 0), 1) * 255 + 0.5)
+            rgba[4 * p + 3] = 255
+        }
+        if (params.canvas) fs.writeFileSync(params.canvas, encodePNG(rgba, w, h))
+        return rgba
+    }
+    return { draw }
+}
+
 function encodePNG(rgba, w, h) {
     const crcTable = new Int32Array(256).map((_, n) => { let c = n; for (let k = 0; k < 8; k++) c = c & 1 ? 0xedb88320 ^ (c >>> 1) : c >>> 1; return c })
     const crc = buf => { let c = -1; for (const b of buf) c = crcTable[(c ^ b) & 255] ^ (c >>> 8); return (c ^ -1) >>> 0 }
@@ -191,4 +233,4 @@ function encodePNG(rgba, w, h) {
     return Buffer.concat([Buffer.from([137, 80, 78, 71, 13, 10, 26, 10]), chunk("IHDR", ihdr), chunk("IDAT", zlib.deflateSync(raw)), chunk("IEND", Buffer.alloc(0))])
 }
 
-module.exports = { requestDevice, initScene, initPathTracer, initDisplay, parseObj, computeTransformMatrices, getTransformedBoundingBox, encodePNG }
+module.exports = { requestDevice, initScene, initPathTracer, initDisplay, initDebugView, parseObj, computeTransformMatrices, getTransformedBoundingBox, encodePNG }

@@ -323,6 +323,27 @@ def test_extensions_closed_forms_and_reset(pta, device):
         device.call("pt_render_set_extensions", C.byref(pta.capi.PtRenderExt()))
 
 
+def test_debug_view(pta, orc, device, built):
+    """the rt-debug visualiser over pt_trace_rays.  Seen from above, the floor is uniformly its normal
+    (0,0,1) -> blue; on the Cornell box the per-pixel hits are the oracle's and the index view encodes them."""
+    desc, s, o = built("floor")
+    top = {"position": [10, 10, 8], "lookAt": [10, 10.001, 0], "fov": 40}
+    img = pta.init_debug_view({"device": device, "scene": s, "image": {"width": 32, "height": 24}, "camera": top}).draw()
+    assert np.all(img == np.array([0, 0, 255, 255], np.uint8))
+    desc, s, o = built("cornell")
+    dv = pta.init_debug_view({"device": device, "scene": s, "image": {"width": 48, "height": 32}, "camera": desc["camera"]})
+    ro, rd = dv.rays()
+    ho, ht, hd = o.trace_rays(ro, rd)
+    idx = dv.draw("index").reshape(-1, 4)
+    hit = ho >= 0
+    assert hit.mean() > 0.5
+    want_r = (np.clip(ho[hit] / np.float32(20.0), 0, 1) * 255.0 + 0.5).astype(np.uint8)
+    np.testing.assert_array_equal(idx[hit, 0], want_r)
+    assert np.all(idx[~hit, :3] == 0)
+    nrm = dv.draw("normal").reshape(-1, 4)
+    assert len(np.unique(nrm[hit, :3], axis=0)) >= 3 and np.all(nrm[~hit, :3] == 0)
+
+
 def test_error_behaviour(pta, device):
     """Reference: console.warn + undefined (scene.js:149,525); here: negative status + message."""
     dev2 = pta.request_device(0)

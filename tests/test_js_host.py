@@ -82,3 +82,42 @@ def test_node_render_equals_python_host_render(pta, device, ext):
     disp = pta.init_display({"device": device, "image": {"buffer": pt.get_image_buffer(), "width": w, "height": h}})
     assert rep["firstPixel"] == disp.draw()[0, 0].tolist()
     assert os.path.getsize("/tmp/node_frame.png") > 100
+
+
+@needs_node
+@pytest.mark.gpu
+def test_node_debug_view_equals_python_debug_view(pta, device):
+    """initDebugView (JS) and init_debug_view (Python) draw the same normal view of the same scene."""
+    code = """
+const pt = require('./pt-host.js')
+const FLOOR = "v -10.0 -10.0 0.0\\nv  10.0 -10.0 0.0\\nv  10.0  10.0 0.0\\nv -10.0  10.0 0.0\\n\\nf 1 2 3\\nf 1 3 4"
+const BOX = ["v -0.5 -0.5 0", "v 0.5 -0.5 0", "v 0.5 0.5 0", "v -0.5 0.5 0", "v -0.5 -0.5 1.4", "v 0.5 -0.5 1.4", "v 0.5 0.5 1.4", "v -0.5 0.5 1.4",
+             "f 1 4 3 2", "f 5 6 7 8", "f 1 2 6 5", "f 3 4 8 7", "f 1 5 8 4", "f 2 3 7 6"].join("\\n")
+;(async () => {
+  const device = pt.requestDevice(0), scene = pt.initScene(device)
+  const box = scene.registerMesh({file: BOX}), floor = scene.registerMesh({file: FLOOR})
+  scene.instanceMesh(box, [9, 9, -1.3], [0, 0, 0.5], [2, 2, 2], 1)
+  scene.instanceMesh(floor, [10, 10, -1.3], [0, 0, 0], [5, 5, 5], 0)
+  await scene.build()
+  const dv = pt.initDebugView({device, scene, image: {width: 40, height: 30}, camera: {position: [15, 15, 5], lookAt: [10, 10, 0]}})
+  const rgba = dv.draw(), idx = dv.draw("index")
+  let sum = 0, sum2 = 0; for (let i = 0; i < rgba.length; i++) { sum += rgba[i] * (1 + i % 7); sum2 += idx[i] * (1 + i % 5) }
+  console.log(JSON.stringify({sum, sum2}))
+  device.destroy()
+})().catch(e => { console.error(e); process.exit(1) })
+"""
+    r = subprocess.run([NODE, "-e", code], cwd=JS, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    scene = pta.init_scene(device)
+    box = scene.register_mesh({"file": BOX}); floor = scene.register_mesh({"file": pta.scenes.FLOOR_OBJ})
+    scene.instance_mesh(box, [9, 9, -1.3], [0, 0, 0.5], [2, 2, 2], 1)
+    scene.instance_mesh(floor, [10, 10, -1.3], [0, 0, 0], [5, 5, 5], 0)
+    scene.build()
+    dv = pta.init_debug_view({"device": device, "scene": scene, "image": {"width": 40, "height": 30},
+                              "camera": {"position": [15, 15, 5], "lookAt": [10, 10, 0]}})
+    a, b = dv.draw().reshape(-1).astype(np.int64), dv.draw("index").reshape(-1).astype(np.int64)
+    i = np.arange(a.size)
+    # rays are built in f32 on both hosts; a pixel whose ray grazes an edge may resolve differently in the last bit
+    assert abs(rep["sum"] - int((a * (1 + i % 7)).sum())) <= 255 * 7 * 4
+    assert abs(rep["sum2"] - int((b * (1 + i % 5)).sum())) <= 255 * 5 * 4
