@@ -29,7 +29,7 @@ struct Mesh {
 }  // namespace
 
 struct pt_ctx {
-    int device = 0; int n_cus = 256; int extend_variant = 0; hipStream_t stream = nullptr; bool own_stream = false; std::string err;
+    int device = 0; int extend_variant = 0; hipStream_t stream = nullptr; bool own_stream = false; std::string err;
     std::vector<Mesh> meshes;
     // scene
     bool scene_built = false; int64_t n_tris = 0; int n_objects = 0; int n_meshes_used = 0;
@@ -175,8 +175,6 @@ int pt_create(int device_id, pt_ctx** out) {
         delete c; return fail(nullptr, PT_ERR_HIP, "pt_create: hipSetDevice/hipStreamCreate failed");
     }
     c->own_stream = true;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount;
     c->extend_variant = 2;   // 64-thread workgroups, 16 LDS stack entries (8 waves/SIMD), longer ray class first (tools/extend_ab.py)
     if (const char* v = getenv("PT_EXTEND_VARIANT")) c->extend_variant = atoi(v);
     *out = c;
@@ -569,7 +567,6 @@ int pt_extend_replay(pt_ctx* c, int variant, int reps, double* avg_us) {
     SceneView sv = scene_view(c);
     double total_ms = 0;
     for (int i = 0; i < reps; i++) {   // the kernel only reads path_o/path_d and rewrites the same hit_obj/hit_tri: idempotent
-        HIPOK(c, hipMemsetAsync(&c->d_hdr->work_counter, 0, 4, c->stream));
         HIPOK(c, hipEventRecord(e0, c->stream));
         ptk_extend_queue(c->ps, c->rc, sv, c->d_hdr, c->d_cam_q, c->d_mat_q, c->d_spill, 0, variant, nullptr, nullptr, nullptr, c->stream);
         HIPOK(c, hipEventRecord(e1, c->stream));

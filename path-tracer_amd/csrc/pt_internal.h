@@ -7,7 +7,8 @@
 #define PT_BLOCK 256                 // threads per workgroup: 4 wave64
 #define PT_STEP_BLOCK 1024           // logic / compaction workgroups: 16 wave64, one count record per 1024 slots
 #define PT_STACK_SIZE 64             // traversal stack entries per ray (reference: 32, scene.js:305)
-#define PT_LDS_STACK 24              // of which the first PT_LDS_STACK live in LDS, the rest in an HBM spill
+#define PT_LDS_STACK 24              // pt_trace_rays (256-thread workgroups): the first PT_LDS_STACK entries live in LDS, the rest
+                                     // in an HBM spill; the render's extend variants choose their own split (pt_kernels_extend.hip)
 #define PT_MAX_ITERS (1 << 20)       // traversal loop guard (degenerate N=1 trees can self-loop)
 #define PT_SAMPLES_PER_TICKET 8      // logic.js:6 SAMPLES_PER_PIXEL_PER_PATH
 
@@ -53,8 +54,7 @@ struct StepHeader {
     unsigned long long overflow; // rays stopped by the stack / iteration guards
     unsigned long long visits[64][4];   // n_inner, n_leaf, n_enter, n_leave (counting variant only), spread over 64 slots
                                         // so that one word does not serialise every wave's atomic; summed by the host
-    int32_t  blocks_done, pad;   // arrival counter of the logic workgroups (the last one runs the scan)
-    int32_t  step_index, work_counter;   // work_counter: next ray-queue entry for the persistent extend kernel
+    int32_t  step_index, pad;
     // Dispatch order of the extend kernel (performance only, results do not depend on it): sampled waves report their trip
     // count (the longest lane's) per ray class, the scan of the next step puts the class that held the longest wave first.
     uint32_t cls_max[32][2];             // {camera, bounce} maximum trips of a wave, spread over 32 cells

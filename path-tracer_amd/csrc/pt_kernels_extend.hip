@@ -169,7 +169,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView 
     int n_cam = hdr->n_camera, n_rays = n_cam + hdr->n_material;
     // ORDER 2: a launch lasts as long as its longest wave plus the time that wave waited to start
     // (profiles/r01_wave_timeline_*), so the class of rays that held the longest wave in the previous step is dispatched
-    // first: queue order when that was a camera wave, reversed when it was a bounce wave (k_scan decides).
+    // first: queue order when that was a camera wave, reversed when it was a bounce wave (workgroup 0 of the compaction launch decides).
     int nblk = (n_rays + BLOCK - 1) / BLOCK;
     int blk = (ORDER == 2 && hdr->extend_order) ? nblk - 1 - (int)blockIdx.x : (int)blockIdx.x;
     if (blk < 0 || blk >= nblk) return;

@@ -1,11 +1,13 @@
 // pt_kernels_render.hip -- the wavefront integrator on gfx950 (extend is in pt_kernels_extend.hip).
 //
-// One step() = logic -> compact+generate+shade -> extend: three launches on one stream, no host round trip in
+// One step() = count -> compact+generate+shade -> extend(+logic): three launches on one stream, no host round trip in
 // between (the reference awaits the queue after each of its four dispatches, path-tracer.js:86-107).  The thread
 // that compacts a slot also produces the slot's next ray: the camera ray as soon as the pixel ticket is known, or
-// the bounce ray (the camera and material kernels only touch their slot's own state).
-// Queue appends are order-preserving: wave64 ballots give each lane its rank, the per-workgroup counts in front of a
-// workgroup give it its base (no scan launch), so every queue is in ascending path-slot order and pixel tickets are handed out in slot order (the reference's canonical serial order; its own order is a race,
+// the bounce ray (the camera and material kernels only touch their slot's own state); the thread that traced a slot's
+// ray runs the slot's logic for the next step (pt_kernels_extend.hip).
+// Queue appends are order-preserving: wave64 ballots give each lane its rank, the count records in front of a
+// workgroup give it its base (no scan launch), so every queue is in ascending path-slot order and pixel tickets are
+// handed out in slot order (the reference's canonical serial order; its own order is a race,
 // logic.js:158,168,205,213).  Because every camera-queue and every material-queue entry produces exactly one
 // ray, the ray-trace queue (QueuesStage3.ray_trace_queue) is the concatenation camera ++ material and is
 // never stored.
@@ -112,7 +114,6 @@ __global__ __launch_bounds__(PT_BLOCK) void k_compact_generate_shade(PathState p
             hdr->total_samples += t.w;
             if (t.x + t.y == 0 && hdr->first_empty_step < 0) hdr->first_empty_step = hdr->step_index;
             hdr->step_index += 1;
-            hdr->work_counter = 0;
         }
     }
     int4 off = make_int4(0, 0, 0, 0);
