@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--fast", action="store_true", help="fast mode: 4-wide BVH traversal (pt_set_traversal_mode; outside the bit-exact contract, reported separately)")
     ap.add_argument("--no-extend-timing", action="store_true", help="leave the HIP events around the extend launches out (roofline fields become 0)")
     ap.add_argument("--config", default="cornell", choices=sorted(CONFIGS))
     ap.add_argument("--width", type=int, default=0)
@@ -83,6 +84,8 @@ def main():
 
     stream = torch.cuda.current_stream().cuda_stream
     dev = pta.request_device(gpu, stream=stream)
+    if args.fast:
+        dev.call("pt_set_traversal_mode", pta.capi.PT_TRAVERSAL_WIDE)
     t0 = time.time()
     scene = pta.scenes.populate(pta.init_scene(dev), desc)
     scene.build()
@@ -148,7 +151,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {info.n_tris} tris / {info.n_objects} instances, {w}x{h}, {spp} spp per GPU, "
-                                   f"{args.paths} path slots (reference: 1000000), reference bounce rules", "spp_total": spp * world,
+                                   f"{args.paths} path slots (reference: 1000000), reference bounce rules" + (", FAST MODE: 4-wide BVH traversal, not bit-exact" if args.fast else ""), "spp_total": spp * world,
                        "parallelism": f"spp-split x{world}, RCCL sum-reduce of the accumulation buffer"},
             "samples_per_s": round(all_samples / elapsed, 1),
             "rays_per_render_per_gpu": rays // args.steps, "wavefront_iterations_per_render": int(steps_per_render),

@@ -156,6 +156,16 @@ int pt_path_state_read(pt_ctx* ctx, const char* field, void* out, size_t bytes);
 /* stage-2 queues of the last step: which = 0 camera_queue, 1 material_queue. *n_io in: capacity, out: count */
 int pt_queue_read(pt_ctx* ctx, int which, int32_t* out, int64_t* n_io);
 
+/* ---- fast mode (NO reference counterpart, OUTSIDE the bit-exact contract, default off) ----
+ * PT_TRAVERSAL_WIDE: inside an object the extend kernel walks a 4-wide collapse of the reference's binary BVH (each inner
+ * child replaced by its two children: up to four boxes per fetch, about half the dependent fetches per ray).  The closest
+ * hit is the same up to ties between equidistant triangles; visit order, visit counts and the low bits of hit_dist differ
+ * (the reference carries hit_dist through its object-space round trips, which then happen at other moments), so path
+ * state is no longer bit-comparable with the oracle: images agree statistically, sample counts exactly.  The reference-exact
+ * buffers (pt_get_*) are unchanged; the collapse costs 128 B per triangle of extra device memory. */
+enum { PT_TRAVERSAL_REFERENCE = 0, PT_TRAVERSAL_WIDE = 1 };
+int pt_set_traversal_mode(pt_ctx* ctx, int mode);
+
 /* ---- measurement hooks (no reference counterpart; used by tools/ and bench.py only) ---- */
 /* The extend stage exists in several variants that differ in ray-to-lane mapping and stack placement, never in
  * results.  pt_extend_variants returns how many there are and copies the name of `variant`. */

@@ -38,6 +38,7 @@ class PtRunStats(C.Structure):
                 ("traversal_bytes", C.c_int64)]
 
 
+PT_TRAVERSAL_REFERENCE, PT_TRAVERSAL_WIDE = 0, 1
 PT_MAT_LAMBERT, PT_MAT_EMITTER, PT_MAT_MIRROR, PT_MAX_EXT_MATERIALS = 0, 1, 2, 14
 
 
@@ -78,6 +79,7 @@ SIGNATURES = {
     "pt_queue_read": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int64)]),
     "pt_extend_variants": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]),
     "pt_set_extend_variant": (C.c_int, [C.c_void_p, C.c_int]),
+    "pt_set_traversal_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "pt_extend_replay": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "pt_extend_wave_log": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "pt_tonemap_rgba8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),

@@ -41,6 +41,7 @@ struct pt_ctx {
     int4 *d_blk_counts = nullptr; int32_t *d_cam_q = nullptr, *d_mat_q = nullptr, *d_spill = nullptr;
     StepHeader* d_hdr = nullptr; StepHeader* h_hdr = nullptr; int nblocks = 0; int64_t step = 0;
     float4* d_ext_mats = nullptr; int n_ext_mats = 0;   // extension materials (pt_render_set_extensions)
+    float4* d_wide = nullptr; int traversal_mode = 0;   // fast mode (pt_set_traversal_mode): 4-wide collapse of the packed BLAS
     std::vector<std::pair<void*, size_t>> render_allocs; std::vector<hipEvent_t> events; int64_t ticket_begin = 0;
 };
 
@@ -67,6 +68,7 @@ void dfree(void* p) { if (p) (void)hipFree(p); }
 
 SceneView scene_view(const pt_ctx* c) {
     SceneView v; v.tlas = c->d_tlas_nodes; v.objects = c->d_objects; v.blas = c->d_blas_nodes; v.tris = c->d_blas_tris;
+    v.wide = c->traversal_mode == PT_TRAVERSAL_WIDE ? c->d_wide : nullptr;
     v.ext_mats = c->d_ext_mats; v.n_ext_mats = c->n_ext_mats; v.pad = 0;
     return v;
 }
@@ -110,6 +112,7 @@ int build_mesh(pt_ctx* c, Mesh& m) {
 }
 
 void free_scene(pt_ctx* c) {
+    if (c->d_wide) { dfree(c->d_wide); c->d_wide = nullptr; }
     dfree(c->d_blas_nodes); dfree(c->d_blas_tris); dfree(c->d_tlas_nodes); dfree(c->d_objects); dfree(c->d_tlas_perm);
     c->d_blas_nodes = c->d_blas_tris = c->d_tlas_nodes = c->d_objects = nullptr; c->d_tlas_perm = nullptr; c->scene_built = false;
 }
@@ -145,6 +148,18 @@ void enqueue_step(pt_ctx* c, int count_visits, hipEvent_t ev0, hipEvent_t ev1) {
     ptk_extend_queue(c->ps, c->rc, sv, c->d_hdr, c->d_cam_q, c->d_mat_q, c->d_spill, count_visits, c->extend_variant, nullptr, c->d_image, c->d_code, c->stream);
     if (ev1) (void)hipEventRecord(ev1, c->stream);
     c->step++;
+}
+
+// fast mode: the 4-wide collapse of every used mesh's packed BVH (built on demand, dropped with the scene)
+int build_wide(pt_ctx* c) {
+    if (c->d_wide) return PT_OK;
+    int rc;
+    if ((rc = dalloc(c, &c->d_wide, (size_t)c->n_tris * PT_WIDE_QUADS, false))) return rc;
+    for (Mesh& m : c->meshes)
+        if (m.used) ptk_collapse_wide(c->d_blas_nodes, m.tri_offset, m.n, c->d_wide, c->stream);
+    HIPOK(c, hipGetLastError());
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
 }
 
 // fresh StepHeader: no step taken, ticket counter at this GPU's first ticket
@@ -277,7 +292,15 @@ int pt_scene_build(pt_ctx* c, const pt_instance* inst, int n_inst) {
     HIPOK(c, hipStreamSynchronize(c->stream));
     dfree(d_aabb); dfree(d_keys); dfree(d_inst); dfree(d_mesh_off);
     c->scene_built = true;
-    return PT_OK;
+    return c->traversal_mode == PT_TRAVERSAL_WIDE ? build_wide(c) : PT_OK;
+}
+
+int pt_set_traversal_mode(pt_ctx* c, int mode) {
+    if (!c || (mode != PT_TRAVERSAL_REFERENCE && mode != PT_TRAVERSAL_WIDE)) return fail(c, PT_ERR_ARG, "pt_set_traversal_mode: unknown mode");
+    HIPOK(c, hipSetDevice(c->device));
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    c->traversal_mode = mode;
+    return (mode == PT_TRAVERSAL_WIDE && c->scene_built) ? build_wide(c) : PT_OK;
 }
 
 int pt_scene_get_info(pt_ctx* c, pt_scene_info* out) {

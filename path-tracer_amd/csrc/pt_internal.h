@@ -20,6 +20,7 @@ struct SceneView {
     const float4* objects;   // pt_object[n_objects]
     const float4* blas;      // pt_bvh_node[n_tris]
     const float4* tris;      // pt_triangle[n_tris]
+    const float4* wide;      // fast mode only (pt_set_traversal_mode): compressed 4-wide collapse of the BLAS (PT_WIDE_QUADS per node), else null
     const float4* ext_mats;  // extension materials (pt_material = 2 quads each) for material ids 2.., null by default
     int32_t n_ext_mats, pad;
 };
@@ -79,6 +80,17 @@ void ptk_radix_tree(const uint32_t* sorted_keys, int64_t n, int32_t* parents /* 
 void ptk_up_pass(const int32_t* idx, const float4* aabb, const int32_t* parents, int64_t n, float4* nodes /* zeroed */, hipStream_t s);
 void ptk_rearrange(const float4* tris_in, const int32_t* idx, int64_t n, float4* tris_out, hipStream_t s);
 void ptk_pack_mesh(const float4* src_nodes, const float4* src_tris, int64_t n, int32_t offset, float4* dst_nodes, float4* dst_tris, hipStream_t s);
+// Fast mode (outside the bit-exact contract): wide[node] = the binary node `node` with each inner child
+// replaced by that child's two children -- up to four boxes per fetch -- and the boxes quantised to 8 bits per coordinate
+// in a frame slightly larger than their union, rounded outwards (a compressed wide BVH): the traversal is bound by the
+// number of 16-B lane requests it sends to L1, and this node is 4 quads for four children instead of 4 quads for two.
+//   quad 0: frame origin x, y, z (f32) | biased exponents of the three power-of-two steps, one byte each
+//   quad 1: child ref[4] (>= 0 wide node, < 0 triangle leaf, PT_WIDE_EMPTY = unused slot)
+//   quad 2: lo.x[4] | lo.y[4] | lo.z[4] | hi.x[4]   (one byte per child)        quad 3: hi.y[4] | hi.z[4] | 0 | 0
+// child box = origin + q * step.
+#define PT_WIDE_EMPTY 0x7fffffff
+#define PT_WIDE_QUADS 4
+void ptk_collapse_wide(const float4* blas_nodes, int64_t offset, int64_t n, float4* wide, hipStream_t s);
 void ptk_pack_objects(const void* instances /* pt_instance[n] */, const int32_t* tlas_perm, const int32_t* mesh_tri_offset,
                       int n, float4* objects, hipStream_t s);
 hipError_t pt_sort_pairs_u32(void* tmp, size_t* tmp_bytes, const uint32_t* kin, uint32_t* kout,

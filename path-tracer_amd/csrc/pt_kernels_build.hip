@@ -196,6 +196,54 @@ void ptk_rearrange(const float4* in, const int32_t* idx, int64_t n, float4* out,
 void ptk_pack_mesh(const float4* src_nodes, const float4* src_tris, int64_t n, int32_t offset, float4* dst_nodes, float4* dst_tris, hipStream_t s) {
     hipLaunchKernelGGL(k_pack_mesh, grid_for(n), dim3(PT_BLOCK), 0, s, src_nodes, src_tris, n, offset, dst_nodes, dst_tris);
 }
+// ---- fast mode: 4-wide collapse of one packed mesh (nodes [offset, offset + n), inner nodes offset .. offset + n - 2) ----
+__global__ __launch_bounds__(PT_BLOCK) void k_collapse_wide(const float4* __restrict__ bin, int64_t offset, int64_t n, float4* __restrict__ wide) {
+    int64_t i = (int64_t)blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float lo[4][3], hi[4][3]; int ref[4]; int k = 0;
+    for (int s = 0; s < 4; s++) { ref[s] = PT_WIDE_EMPTY; for (int a = 0; a < 3; a++) lo[s][a] = hi[s][a] = 0.0f; }
+    auto slot = [&](int c, float4 mn, float4 mx) { ref[k] = c; lo[k][0] = mn.x; lo[k][1] = mn.y; lo[k][2] = mn.z; hi[k][0] = mx.x; hi[k][1] = mx.y; hi[k][2] = mx.z; k++; };
+    auto child = [&](int c, float4 mn, float4 mx) {
+        if (c >= 0) { const float4* cn = bin + 4 * (int64_t)c; float4 c0 = cn[0], c1 = cn[1], c2 = cn[2], c3 = cn[3];
+                      slot(__float_as_int(c0.w), c0, c1); slot(__float_as_int(c2.w), c2, c3); }
+        else slot(c, mn, mx);
+    };
+    if (i < n - 1 || n == 1) {                      // node n-1 is the unused tail slot of an n-leaf radix tree
+        const float4* nd = bin + 4 * (offset + i);
+        float4 a0 = nd[0], a1 = nd[1], a2 = nd[2], a3 = nd[3];
+        child(__float_as_int(a0.w), a0, a1);
+        if (n > 1) child(__float_as_int(a2.w), a2, a3);   // a one-triangle mesh keeps only its leaf (its r child is the reference's self pointer)
+    }
+    // quantisation frame: the union of the child boxes, padded so that a box on the frame's border still gets slack
+    float fmin[3] = {3e38f, 3e38f, 3e38f}, fmax[3] = {-3e38f, -3e38f, -3e38f};
+    for (int c = 0; c < k; c++) for (int a = 0; a < 3; a++) { fmin[a] = fminf(fmin[a], lo[c][a]); fmax[a] = fmaxf(fmax[a], hi[c][a]); }
+    float org[3] = {0.0f, 0.0f, 0.0f}, step[3] = {1.0f, 1.0f, 1.0f}; unsigned ebits = 0;
+    unsigned qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0};
+    for (int a = 0; a < 3 && k > 0; a++) {
+        float ext = fmax[a] - fmin[a];
+        float pad = fmaxf(fmaxf(ext * 0.002f, fmaxf(fabsf(fmin[a]), fabsf(fmax[a])) * 2e-6f), 1e-30f);
+        org[a] = fmin[a] - pad;
+        float need = ((fmax[a] + pad) - org[a]) / 254.0f;                  // 254: one step of head room for the outward rounding
+        int e; frexpf(need, &e);                                           // need = m * 2^e, m in [0.5, 1)  ->  2^e >= need
+        e = max(-126, min(126, e));
+        step[a] = ldexpf(1.0f, e); ebits |= (unsigned)(e + 127) << (8 * a);
+        for (int c = 0; c < k; c++) {
+            int l = (int)floorf((lo[c][a] - org[a]) / step[a]) , h = (int)ceilf((hi[c][a] - org[a]) / step[a]);
+            l = max(0, min(255, l)); h = max(0, min(255, h));
+            while (l > 0 && fmaf((float)l, step[a], org[a]) > lo[c][a]) l--;       // decoded box must contain the real one
+            while (h < 255 && fmaf((float)h, step[a], org[a]) < hi[c][a]) h++;
+            qlo[a] |= (unsigned)l << (8 * c); qhi[a] |= (unsigned)h << (8 * c);
+        }
+    }
+    float4* w = wide + PT_WIDE_QUADS * (offset + i);
+    w[0] = make_float4(org[0], org[1], org[2], __uint_as_float(ebits));
+    w[1] = make_float4(__int_as_float(ref[0]), __int_as_float(ref[1]), __int_as_float(ref[2]), __int_as_float(ref[3]));
+    w[2] = make_float4(__uint_as_float(qlo[0]), __uint_as_float(qlo[1]), __uint_as_float(qlo[2]), __uint_as_float(qhi[0]));
+    w[3] = make_float4(__uint_as_float(qhi[1]), __uint_as_float(qhi[2]), 0.0f, 0.0f);
+}
+void ptk_collapse_wide(const float4* blas_nodes, int64_t offset, int64_t n, float4* wide, hipStream_t s) {
+    hipLaunchKernelGGL(k_collapse_wide, grid_for(n), dim3(PT_BLOCK), 0, s, blas_nodes, offset, n, wide);
+}
 void ptk_pack_objects(const void* instances, const int32_t* perm, const int32_t* mesh_tri_offset, int n, float4* objects, hipStream_t s) {
     hipLaunchKernelGGL(k_pack_objects, grid_for(n), dim3(PT_BLOCK), 0, s, (const float*)instances, perm, mesh_tri_offset, n, objects);
 }

@@ -78,7 +78,19 @@ __device__ __forceinline__ void switch_space(float4 r0, float4 r1, float4 r2, Ra
 }
 
 // One trip through the reference's while loop (scene.js:328-440).  Returns false when the loop ends.
-template <bool COUNT, class STK>
+// fast mode: order two (distance, child) pairs, nearer first
+__device__ __forceinline__ void near_first(float& ka, int& ra, float& kb, int& rb) {
+    bool sw = kb < ka;
+    float k = sw ? kb : ka; int rr = sw ? rb : ra;
+    kb = sw ? ka : kb; rb = sw ? ra : rb; ka = k; ra = rr;
+}
+
+// WIDE (fast mode): inside an object the nodes are the compressed 4-wide collapse (SceneView::wide, layout in
+// pt_internal.h): one 64-B fetch tests up to four (outward-rounded) boxes, the nearest valid child is taken and the others
+// are pushed farthest first.  Same closest hit up to ties;
+// visit order, visit counts and the low bits of hit_dist differ from the reference's (hit_dist is carried through the
+// object-space round trips, which happen at different moments).  The TLAS stays binary.
+template <bool COUNT, class STK, bool WIDE = false>
 __device__ __forceinline__ bool trav_step(const SceneView& sc, Ray& r, const STK& stk) {
     if (r.sp < 0) return false;
     if (++r.iter > PT_MAX_ITERS) { r.overflow = 1; return false; }
@@ -102,6 +114,36 @@ __device__ __forceinline__ bool trav_step(const SceneView& sc, Ray& r, const STK
             if (dist > 0.0f && dist < r.hit_dist) { r.hit_dist = dist; r.hit_tri = t; r.hit_obj = r.obj; }
             if (COUNT) r.n_leaf++;
             r.sp -= 1; r.node = stk.get(r.sp);
+        }
+    } else if (WIDE && r.obj >= 0) {                            // fast mode: 4-wide BLAS node
+        const float4* nd = sc.wide + PT_WIDE_QUADS * (int64_t)r.node;
+        float4 h = nd[0], rf = nd[1], qa = nd[2], qb = nd[3];
+        if (COUNT) r.n_inner++;                                 // one 64-B record
+        unsigned eb = __float_as_uint(h.w);
+        f3 org = F3(h), st = F3(__uint_as_float((eb & 0xffu) << 23), __uint_as_float(((eb >> 8) & 0xffu) << 23), __uint_as_float(((eb >> 16) & 0xffu) << 23));
+        unsigned lx = __float_as_uint(qa.x), ly = __float_as_uint(qa.y), lz = __float_as_uint(qa.z), hx = __float_as_uint(qa.w),
+                 hy = __float_as_uint(qb.x), hz = __float_as_uint(qb.y);
+        int r0 = __float_as_int(rf.x), r1 = __float_as_int(rf.y), r2 = __float_as_int(rf.z), r3 = __float_as_int(rf.w);
+        const float INF = __builtin_inff();
+        auto child_t = [&](int c, int ref) -> float {
+            int sh = 8 * c;
+            f3 lo = F3(__builtin_fmaf((float)((lx >> sh) & 0xffu), st.x, org.x), __builtin_fmaf((float)((ly >> sh) & 0xffu), st.y, org.y),
+                       __builtin_fmaf((float)((lz >> sh) & 0xffu), st.z, org.z));
+            f3 hi = F3(__builtin_fmaf((float)((hx >> sh) & 0xffu), st.x, org.x), __builtin_fmaf((float)((hy >> sh) & 0xffu), st.y, org.y),
+                       __builtin_fmaf((float)((hz >> sh) & 0xffu), st.z, org.z));
+            float t = slab(lo, hi, r.o, r.id);
+            return (ref != PT_WIDE_EMPTY && t != -1e30f && t < r.hit_dist) ? t : INF;
+        };
+        float k0 = child_t(0, r0), k1 = child_t(1, r1), k2 = child_t(2, r2), k3 = child_t(3, r3);
+        near_first(k0, r0, k1, r1); near_first(k2, r2, k3, r3); near_first(k0, r0, k2, r2); near_first(k1, r1, k3, r3); near_first(k1, r1, k2, r2);
+        int nv = (k0 != INF) + (k1 != INF) + (k2 != INF) + (k3 != INF);
+        if (nv == 0) { r.sp -= 1; r.node = stk.get(r.sp); }
+        else {
+            if (r.sp + nv - 1 > PT_STACK_SIZE) { r.overflow = 1; return false; }
+            if (nv > 3) { stk.put(r.sp, r3); r.sp += 1; }
+            if (nv > 2) { stk.put(r.sp, r2); r.sp += 1; }
+            if (nv > 1) { stk.put(r.sp, r1); r.sp += 1; }
+            r.node = r0;
         }
     } else {                                                    // :392-439 inner node
         const float4* nd = (r.obj < 0 ? sc.tlas : sc.blas) + 4 * (int64_t)r.node;
@@ -159,7 +201,7 @@ __device__ __forceinline__ void publish(unsigned long long ov, unsigned long lon
 // the slot's own state, the hit is still in registers, and its memory traffic hides under the traversal of the other
 // waves instead of costing a launch.  (The material sample too was tried here: its ~90 registers take the traversal from
 // 8 to 5 waves per SIMD, +30 us per launch; capped at 64 registers it spills, +43 us.  It runs in the compaction launch.)
-template <int LDS_N, int BLOCK, bool COUNT, int ORDER, bool LOG, bool LOGIC>
+template <int LDS_N, int BLOCK, bool COUNT, int ORDER, bool LOG, bool LOGIC, bool WIDE = false>
 __global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView sc, StepHeader* hdr, const int32_t* __restrict__ cam_q,
                                                         const int32_t* __restrict__ mat_q, int32_t* spill, int64_t spill_stride,
                                                         unsigned long long* wave_log, float* __restrict__ image, uint8_t* __restrict__ code_out,
@@ -180,7 +222,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView 
         int path = q < n_cam ? cam_q[q] : mat_q[q - n_cam];
         ray_init(r, F3(ps.path_o[path]), F3(ps.path_d[path]));
         Stack<LDS_N, BLOCK> stk{s_stack + threadIdx.x, spill + q, spill_stride};
-        while (trav_step<COUNT>(sc, r, stk)) {}
+        while (trav_step<COUNT, Stack<LDS_N, BLOCK>, WIDE>(sc, r, stk)) {}
         trav_finish<COUNT>(sc, r);
         ps.hit_obj[path] = r.hit_obj; ps.hit_tri[path] = r.hit_tri;
         if (LOGIC) {
@@ -212,6 +254,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView 
 // --------------------------------------------------------------------------------------------
 // Test hook: caller-supplied rays, always counting (pt_trace_rays)
 // --------------------------------------------------------------------------------------------
+template <bool WIDE>
 __global__ __launch_bounds__(PT_BLOCK) void k_extend_direct(SceneView sc, const float4* __restrict__ o4, const float4* __restrict__ d4, int n,
                                                             int32_t* __restrict__ hit_obj, int32_t* __restrict__ hit_tri,
                                                             float* __restrict__ hit_dist, int4* __restrict__ counts4, int32_t* spill,
@@ -222,7 +265,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_extend_direct(SceneView sc, const 
     if (q < n) {
         ray_init(r, F3(o4[q]), F3(d4[q]));
         Stack<PT_LDS_STACK, PT_BLOCK> stk{s_stack + threadIdx.x, spill + q, spill_stride};
-        while (trav_step<true>(sc, r, stk)) {}
+        while (trav_step<true, Stack<PT_LDS_STACK, PT_BLOCK>, WIDE>(sc, r, stk)) {}
         trav_finish<true>(sc, r);
         hit_obj[q] = r.hit_obj; hit_tri[q] = r.hit_tri; hit_dist[q] = r.hit_dist;
         if (counts4) counts4[q] = make_int4(r.n_inner, r.n_leaf, r.n_enter, r.n_leave);
@@ -235,13 +278,13 @@ static int64_t pad_to(int64_t n, int64_t m) { return (n + m - 1) / m * m; }
 // The spill is sized for the smallest LDS share any variant uses (16 entries) and the largest slot count.
 size_t ptk_spill_ints(int64_t n_rays) { return (size_t)pad_to(n_rays, 256) * (PT_STACK_SIZE - 16); }
 
-template <int LDS_N, int BLOCK, int ORDER>
+template <int LDS_N, int BLOCK, int ORDER, bool WIDE = false>
 static void launch_queue(const PathState& ps, int num_paths, const SceneView& sc, StepHeader* hdr, const int32_t* cam_q,
                          const int32_t* mat_q, int32_t* spill, int count, unsigned long long* wave_log, float* image, uint8_t* code, int max_nb,
                          hipStream_t s) {
     int64_t stride = pad_to(num_paths, 256);
     dim3 grid((unsigned)((num_paths + BLOCK - 1) / BLOCK));
-#define PT_LAUNCH(COUNT, LOG, LOGIC) hipLaunchKernelGGL((k_extend_queue<LDS_N, BLOCK, COUNT, ORDER, LOG, LOGIC>), grid, dim3(BLOCK), 0, s, ps, sc, hdr, \
+#define PT_LAUNCH(COUNT, LOG, LOGIC) hipLaunchKernelGGL((k_extend_queue<LDS_N, BLOCK, COUNT, ORDER, LOG, LOGIC, WIDE>), grid, dim3(BLOCK), 0, s, ps, sc, hdr, \
                                                        cam_q, mat_q, spill, stride, wave_log, image, code, max_nb)
     if (wave_log)    PT_LAUNCH(false, true, false);    // measurement replays (code == null): traversal only, idempotent
     else if (!code)  PT_LAUNCH(false, false, false);
@@ -270,7 +313,8 @@ const char* ptk_extend_variant_name(int v) { return (v >= 0 && v < 3) ? kVariant
 void ptk_extend_queue(const PathState& ps, const RenderConst& rc, const SceneView& sc, StepHeader* hdr, const int32_t* cam_q,
                       const int32_t* mat_q, int32_t* spill, int count, int variant, unsigned long long* wave_log, float* image, uint8_t* code,
                       hipStream_t s) {
-    if (variant == 0)      launch_queue<24, 256, 1>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rc.max_nb, s);
+    if (sc.wide)           launch_queue<16, 64, 2, true>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rc.max_nb, s);   // fast mode
+    else if (variant == 0) launch_queue<24, 256, 1>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rc.max_nb, s);
     else if (variant == 1) launch_queue<16, 64, 1>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rc.max_nb, s);
     else                   launch_queue<16, 64, 2>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rc.max_nb, s);
 }
@@ -280,6 +324,8 @@ int64_t ptk_extend_waves(int num_paths, int variant) {
 }
 void ptk_extend_direct(const SceneView& sc, const float4* o4, const float4* d4, int n, int32_t* hit_obj, int32_t* hit_tri,
                        float* hit_dist, int4* counts4, int32_t* spill, StepHeader* hdr, hipStream_t s) {
-    hipLaunchKernelGGL(k_extend_direct, dim3((unsigned)((n + PT_BLOCK - 1) / PT_BLOCK)), dim3(PT_BLOCK), 0, s, sc, o4, d4, n, hit_obj,
+    if (sc.wide) hipLaunchKernelGGL(k_extend_direct<true>, dim3((unsigned)((n + PT_BLOCK - 1) / PT_BLOCK)), dim3(PT_BLOCK), 0, s, sc, o4, d4, n, hit_obj,
+                       hit_tri, hit_dist, counts4, spill, pad_to(n, 256), hdr);
+    else hipLaunchKernelGGL(k_extend_direct<false>, dim3((unsigned)((n + PT_BLOCK - 1) / PT_BLOCK)), dim3(PT_BLOCK), 0, s, sc, o4, d4, n, hit_obj,
                        hit_tri, hit_dist, counts4, spill, pad_to(n, 256), hdr);
 }

@@ -344,6 +344,71 @@ def test_debug_view(pta, orc, device, built):
     assert len(np.unique(nrm[hit, :3], axis=0)) >= 3 and np.all(nrm[~hit, :3] == 0)
 
 
+ONE_TRI = "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3"
+
+
+def test_fast_mode_closest_hits(pta, device, built):
+    """SURVEY 8f.4 fast mode (compressed 4-wide BVH; outside the bit-exact contract): the closest hit is the reference-exact
+    mode's except for ties between equidistant triangles; hit distances agree to 1e-6 relative."""
+    one_tri = {"meshes": [{"file": ONE_TRI}, {"file": pta.scenes.FLOOR_OBJ}],
+               "instances": [(0, [0, 0, 1], [0.3, 0.2, 0.1], [2, 2, 2], 0), (0, [1, 1, 2], [0, 0, 0], [1, 1, 1], 1), (1, [0, 0, 0], [0, 0, 0], [1, 1, 1], 0)],
+               "camera": {"position": [0.5, 0.5, 6], "lookAt": [0.5, 0.6, 0], "fov": 30}}
+    rng = np.random.default_rng(11)
+    dev2 = pta.request_device(0)                      # its own context: `built` keeps one scene per context
+    try:
+        for name in ("cornell", "sphere", "instanced", "one_triangle_meshes"):
+            if name == "one_triangle_meshes":
+                desc, dev = one_tri, dev2
+                s = pta.scenes.populate(pta.init_scene(dev2), desc); s.build()
+            else:
+                (desc, s, _), dev = built(name), device
+            cam, look = np.asarray(desc["camera"]["position"], np.float32), np.asarray(desc["camera"]["lookAt"], np.float32)
+            n = 200_000
+            d = (look - cam)[None, :] + rng.normal(size=(n, 3)).astype(np.float32) * np.linalg.norm(look - cam) * 0.35
+            d /= np.linalg.norm(d, axis=1, keepdims=True)
+            o = np.broadcast_to(cam, (n, 3)).copy()
+            dev.call("pt_set_traversal_mode", pta.capi.PT_TRAVERSAL_REFERENCE)
+            a = s.trace_rays(o, d)
+            dev.call("pt_set_traversal_mode", pta.capi.PT_TRAVERSAL_WIDE)
+            b = s.trace_rays(o, d)
+            np.testing.assert_array_equal(a[0] >= 0, b[0] >= 0, err_msg=name)            # hit / miss never changes
+            same = (a[0] == b[0]) & (a[1] == b[1])
+            assert same.mean() > 0.9995, (name, same.mean())
+            rel = np.abs(a[2] - b[2]) / np.maximum(np.abs(a[2]), 1e-6)
+            assert rel.max() < 1e-6, (name, rel.max())                                   # a different index only on a tie
+            assert (a[0] >= 0).mean() > 0.1
+    finally:
+        device.call("pt_set_traversal_mode", pta.capi.PT_TRAVERSAL_REFERENCE)
+        dev2.destroy()
+
+
+def test_fast_mode_render(pta, orc, device, built):
+    """A fast-mode render: every pixel gets exactly spp samples, the frame agrees with the reference-exact frame statistically
+    (paths fork where a hit distance differs in its last bits), and switching back restores bit-exact oracle parity."""
+    desc, s, o = built("cornell")
+    w, h, spp, paths = 96, 54, 64, 20000
+    def render():
+        pt = pta.init_path_tracer({"device": device, "scene": s, "image": {"width": w, "height": h}, "camera": desc["camera"],
+                                   "settings": {"samples": spp, "numPaths": paths}})
+        rs = pt.run()
+        return pt, rs, pt.read_image()
+    try:
+        device.call("pt_set_traversal_mode", pta.capi.PT_TRAVERSAL_WIDE)
+        _, rs_f, img_f = render()
+    finally:
+        device.call("pt_set_traversal_mode", pta.capi.PT_TRAVERSAL_REFERENCE)
+    pt, rs_e, img_e = render()
+    assert rs_f.total_samples == rs_e.total_samples == w * h * spp and rs_f.stack_overflows == 0
+    np.testing.assert_array_equal(img_f[..., 3], np.full((h, w), spp, np.float32))
+    rad_f, rad_e = img_f[..., :3] / spp, img_e[..., :3] / spp
+    assert abs(rad_f.mean() / rad_e.mean() - 1) < 0.01
+    rmse = np.sqrt(((rad_f - rad_e) ** 2).mean()) / rad_e.mean()
+    assert rmse < 0.08, rmse                                                     # two 64-spp estimates of the same image
+    orr = orc.OrcRender(o, w, h, desc["camera"], spp, paths); orr.run()
+    np.testing.assert_array_equal(img_e[..., 3], orr.image()[..., 3])
+    np.testing.assert_allclose(img_e[..., :3], orr.image()[..., :3], rtol=1e-5, atol=1e-6)
+
+
 def test_error_behaviour(pta, device):
     """Reference: console.warn + undefined (scene.js:149,525); here: negative status + message."""
     dev2 = pta.request_device(0)
