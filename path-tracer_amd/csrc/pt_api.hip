@@ -66,6 +66,17 @@ template <typename T> int dalloc(pt_ctx* c, T** p, size_t count, bool zero) {
 }
 void dfree(void* p) { if (p) (void)hipFree(p); }
 
+// Device temporaries of one call: released on every exit path, error returns included.
+struct Tmp {
+    std::vector<void*> held;
+    ~Tmp() { for (void* p : held) (void)hipFree(p); }
+    template <typename T> int alloc(pt_ctx* c, T** p, size_t count, bool zero) {
+        int rc = dalloc(c, p, count, zero);
+        if (rc == PT_OK) held.push_back(*p);
+        return rc;
+    }
+};
+
 SceneView scene_view(const pt_ctx* c) {
     SceneView v; v.tlas = c->d_tlas_nodes; v.objects = c->d_objects; v.blas = c->d_blas_nodes; v.tris = c->d_blas_tris;
     v.wide = c->traversal_mode == PT_TRAVERSAL_WIDE ? c->d_wide : nullptr;
@@ -75,29 +86,29 @@ SceneView scene_view(const pt_ctx* c) {
 
 // builders.js:174-192: sort -> radix tree -> up pass.  aabb: 2 quads per primitive; keys are consumed.
 int build_bvh(pt_ctx* c, const float4* d_aabb, uint32_t* d_keys, int64_t n, int32_t* d_perm_out, float4* d_nodes_out) {
-    uint32_t* d_keys_sorted = nullptr; int32_t *d_iota = nullptr, *d_parents = nullptr; void* d_tmp = nullptr; size_t tmp_bytes = 0;
-    int rc = PT_OK;
-    if ((rc = dalloc(c, &d_keys_sorted, (size_t)n, false))) return rc;
-    if ((rc = dalloc(c, &d_iota, (size_t)n, false))) return rc;
-    if ((rc = dalloc(c, &d_parents, (size_t)(2 * n), true))) return rc;
+    uint32_t* d_keys_sorted = nullptr; int32_t *d_iota = nullptr, *d_parents = nullptr; char* d_tmp = nullptr; size_t tmp_bytes = 0;
+    int rc = PT_OK; Tmp tmp;
+    if ((rc = tmp.alloc(c, &d_keys_sorted, (size_t)n, false))) return rc;
+    if ((rc = tmp.alloc(c, &d_iota, (size_t)n, false))) return rc;
+    if ((rc = tmp.alloc(c, &d_parents, (size_t)(2 * n), true))) return rc;
     HIPOK(c, hipMemsetAsync(d_nodes_out, 0, (size_t)n * 64, c->stream));   // WebGPU zero-fills BVH_BUFFER; f_1 is the arrival counter
     ptk_iota(d_iota, n, c->stream);
     HIPOK(c, pt_sort_pairs_u32(nullptr, &tmp_bytes, d_keys, d_keys_sorted, d_iota, d_perm_out, (size_t)n, c->stream));
-    HIPOK(c, hipMalloc(&d_tmp, std::max<size_t>(tmp_bytes, 16)));
+    if ((rc = tmp.alloc(c, &d_tmp, std::max<size_t>(tmp_bytes, 16), false))) return rc;
     HIPOK(c, pt_sort_pairs_u32(d_tmp, &tmp_bytes, d_keys, d_keys_sorted, d_iota, d_perm_out, (size_t)n, c->stream));
     ptk_radix_tree(d_keys_sorted, n, d_parents, c->stream);
     ptk_up_pass(d_perm_out, d_aabb, d_parents, n, d_nodes_out, c->stream);
     HIPOK(c, hipGetLastError());
     HIPOK(c, hipStreamSynchronize(c->stream));
-    dfree(d_keys_sorted); dfree(d_iota); dfree(d_parents); dfree(d_tmp);
     return PT_OK;
 }
 
 // builders.js:153-214 buildMeshBVH
 int build_mesh(pt_ctx* c, Mesh& m) {
-    float4* d_aabb = nullptr; uint32_t* d_keys = nullptr; int rc;
-    if ((rc = dalloc(c, &d_aabb, (size_t)m.n * 2, false))) return rc;
-    if ((rc = dalloc(c, &d_keys, (size_t)m.n, false))) return rc;
+    float4* d_aabb = nullptr; uint32_t* d_keys = nullptr; int rc; Tmp tmp;
+    dfree(m.d_nodes); dfree(m.d_tris_sorted); dfree(m.d_perm); m.d_nodes = m.d_tris_sorted = nullptr; m.d_perm = nullptr;   // a failed earlier attempt
+    if ((rc = tmp.alloc(c, &d_aabb, (size_t)m.n * 2, false))) return rc;
+    if ((rc = tmp.alloc(c, &d_keys, (size_t)m.n, false))) return rc;
     if ((rc = dalloc(c, &m.d_nodes, (size_t)m.n * 4, false))) return rc;
     if ((rc = dalloc(c, &m.d_tris_sorted, (size_t)m.n * 3, false))) return rc;
     if ((rc = dalloc(c, &m.d_perm, (size_t)m.n, false))) return rc;
@@ -106,7 +117,6 @@ int build_mesh(pt_ctx* c, Mesh& m) {
     ptk_rearrange(m.d_tris_in, m.d_perm, m.n, m.d_tris_sorted, c->stream);
     HIPOK(c, hipGetLastError());
     HIPOK(c, hipStreamSynchronize(c->stream));
-    dfree(d_aabb); dfree(d_keys);
     m.built = true;
     return PT_OK;
 }
@@ -274,14 +284,14 @@ int pt_scene_build(pt_ctx* c, const pt_instance* inst, int n_inst) {
             aabbs[8 * i + k] = inst[i].aabb_min[k]; aabbs[8 * i + 4 + k] = inst[i].aabb_max[k];
             sb[k] = fminf(sb[k], inst[i].aabb_min[k]); sb[3 + k] = fmaxf(sb[3 + k], inst[i].aabb_max[k]);
         }
-    float4* d_aabb = nullptr; uint32_t* d_keys = nullptr; void* d_inst = nullptr; int32_t* d_mesh_off = nullptr;
-    if ((rc = dalloc(c, &d_aabb, (size_t)n_inst * 2, false))) return rc;
-    if ((rc = dalloc(c, &d_keys, (size_t)n_inst, false))) return rc;
+    float4* d_aabb = nullptr; uint32_t* d_keys = nullptr; void* d_inst = nullptr; int32_t* d_mesh_off = nullptr; Tmp tmp;
+    if ((rc = tmp.alloc(c, &d_aabb, (size_t)n_inst * 2, false))) return rc;
+    if ((rc = tmp.alloc(c, &d_keys, (size_t)n_inst, false))) return rc;
     if ((rc = dalloc(c, &c->d_tlas_nodes, (size_t)n_inst * 4, false))) return rc;
     if ((rc = dalloc(c, &c->d_tlas_perm, (size_t)n_inst, false))) return rc;
     if ((rc = dalloc(c, &c->d_objects, (size_t)n_inst * 8, false))) return rc;
-    if ((rc = dalloc(c, (char**)&d_inst, (size_t)n_inst * sizeof(pt_instance), false))) return rc;
-    if ((rc = dalloc(c, &d_mesh_off, mesh_off.size(), false))) return rc;
+    if ((rc = tmp.alloc(c, (char**)&d_inst, (size_t)n_inst * sizeof(pt_instance), false))) return rc;
+    if ((rc = tmp.alloc(c, &d_mesh_off, mesh_off.size(), false))) return rc;
     HIPOK(c, hipMemcpyAsync(d_aabb, aabbs.data(), aabbs.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIPOK(c, hipMemcpyAsync(d_inst, inst, (size_t)n_inst * sizeof(pt_instance), hipMemcpyHostToDevice, c->stream));
     HIPOK(c, hipMemcpyAsync(d_mesh_off, mesh_off.data(), mesh_off.size() * 4, hipMemcpyHostToDevice, c->stream));
@@ -290,7 +300,6 @@ int pt_scene_build(pt_ctx* c, const pt_instance* inst, int n_inst) {
     ptk_pack_objects(d_inst, c->d_tlas_perm, d_mesh_off, n_inst, c->d_objects, c->stream);
     HIPOK(c, hipGetLastError());
     HIPOK(c, hipStreamSynchronize(c->stream));
-    dfree(d_aabb); dfree(d_keys); dfree(d_inst); dfree(d_mesh_off);
     c->scene_built = true;
     return c->traversal_mode == PT_TRAVERSAL_WIDE ? build_wide(c) : PT_OK;
 }
@@ -340,10 +349,10 @@ int pt_trace_rays(pt_ctx* c, const float* o3, const float* d3, int64_t n, int32_
     const int64_t CH = 1 << 20;
     int64_t cap = std::min<int64_t>(std::max<int64_t>(n, 1), CH);
     float4 *d_o = nullptr, *d_d = nullptr; int32_t *d_ho = nullptr, *d_ht = nullptr, *d_spill = nullptr; float* d_hd = nullptr; int4* d_cnt = nullptr;
-    StepHeader* d_hdr = nullptr; int rc;
-    if ((rc = dalloc(c, &d_o, (size_t)cap, false)) || (rc = dalloc(c, &d_d, (size_t)cap, false)) || (rc = dalloc(c, &d_ho, (size_t)cap, false)) ||
-        (rc = dalloc(c, &d_ht, (size_t)cap, false)) || (rc = dalloc(c, &d_hd, (size_t)cap, false)) || (rc = dalloc(c, &d_cnt, (size_t)cap, false)) ||
-        (rc = dalloc(c, &d_spill, ptk_spill_ints(cap), false)) || (rc = dalloc(c, &d_hdr, 1, true)))
+    StepHeader* d_hdr = nullptr; int rc; Tmp tmp;
+    if ((rc = tmp.alloc(c, &d_o, (size_t)cap, false)) || (rc = tmp.alloc(c, &d_d, (size_t)cap, false)) || (rc = tmp.alloc(c, &d_ho, (size_t)cap, false)) ||
+        (rc = tmp.alloc(c, &d_ht, (size_t)cap, false)) || (rc = tmp.alloc(c, &d_hd, (size_t)cap, false)) || (rc = tmp.alloc(c, &d_cnt, (size_t)cap, false)) ||
+        (rc = tmp.alloc(c, &d_spill, ptk_spill_ints(cap), false)) || (rc = tmp.alloc(c, &d_hdr, 1, true)))
         return rc;
     std::vector<float> stage((size_t)cap * 4);
     SceneView sv = scene_view(c);
@@ -363,7 +372,6 @@ int pt_trace_rays(pt_ctx* c, const float* o3, const float* d3, int64_t n, int32_
         if (counts4) HIPOK(c, hipMemcpyAsync(counts4 + 4 * base, d_cnt, (size_t)m * 16, hipMemcpyDeviceToHost, c->stream));
         HIPOK(c, hipStreamSynchronize(c->stream));
     }
-    dfree(d_o); dfree(d_d); dfree(d_ho); dfree(d_ht); dfree(d_hd); dfree(d_cnt); dfree(d_spill); dfree(d_hdr);
     return PT_OK;
 }
 
@@ -404,13 +412,11 @@ int pt_render_init(pt_ctx* c, const pt_render_params* p) {
     else { if ((r = ralloc(c, &c->d_image, img_floats))) return r; c->own_image = true; }
     HIPOK(c, hipHostMalloc((void**)&c->h_hdr, 2 * sizeof(StepHeader), hipHostMallocDefault));
     {   // the pixel-independent part of the camera: evaluated by the device (same arithmetic as every other kernel), kept in rc
-        CameraFrame* d_cf = nullptr;
-        if ((r = dalloc(c, &d_cf, 1, true))) return r;
+        CameraFrame* d_cf = nullptr; Tmp tmp;
+        if ((r = tmp.alloc(c, &d_cf, 1, true))) return r;
         ptk_camera_frame(rc, d_cf, c->stream);
         HIPOK(c, hipGetLastError());
-        r = read_back(c, &rc.frame, d_cf, sizeof(CameraFrame));
-        dfree(d_cf);
-        if (r) return r;
+        if ((r = read_back(c, &rc.frame, d_cf, sizeof(CameraFrame)))) return r;
     }
     c->render_ready = true;
     return write_header(c);
@@ -608,13 +614,12 @@ int pt_extend_wave_log(pt_ctx* c, int variant, uint64_t* out, int64_t cap_waves,
     HIPOK(c, hipSetDevice(c->device));
     int64_t n = ptk_extend_waves(c->rc.num_paths, variant);
     if (n > cap_waves) return fail(c, PT_ERR_ARG, "pt_extend_wave_log: buffer too small");
-    unsigned long long* d_log = nullptr; int r;
-    if ((r = dalloc(c, &d_log, (size_t)n * 4, true))) return r;
+    unsigned long long* d_log = nullptr; int r; Tmp tmp;
+    if ((r = tmp.alloc(c, &d_log, (size_t)n * 4, true))) return r;
     SceneView sv = scene_view(c);
     ptk_extend_queue(c->ps, c->rc, sv, c->d_hdr, c->d_cam_q, c->d_mat_q, c->d_spill, 0, variant, d_log, nullptr, nullptr, c->stream);
     HIPOK(c, hipGetLastError());
     r = read_back(c, out, d_log, (size_t)n * 32);
-    dfree(d_log);
     *n_waves = n;
     return r;
 }
@@ -630,13 +635,11 @@ int pt_tonemap_rgba8(pt_ctx* c, const void* image_dev, int32_t width, int32_t he
     if (c->render_ready && image_dev == c->d_image)      // a draw in the middle of a render shows every finished sample
         ptk_flush_tickets(c->ps, c->rc.num_paths, c->d_image, c->stream);
     if (width < 1 || height < 1) return fail(c, PT_ERR_ARG, "pt_tonemap_rgba8: bad size");
-    int64_t n = (int64_t)width * height; uint32_t* d_out = nullptr; int r;
-    if ((r = dalloc(c, &d_out, (size_t)n, false))) return r;
+    int64_t n = (int64_t)width * height; uint32_t* d_out = nullptr; int r; Tmp tmp;
+    if ((r = tmp.alloc(c, &d_out, (size_t)n, false))) return r;
     ptk_tonemap((const float4*)image_dev, n, d_out, c->stream);
     HIPOK(c, hipGetLastError());
-    r = read_back(c, rgba8, d_out, (size_t)n * 4);
-    dfree(d_out);
-    return r;
+    return read_back(c, rgba8, d_out, (size_t)n * 4);
 }
 
 }  // extern "C"
