@@ -81,6 +81,7 @@ SceneView scene_view(const pt_ctx* c) {
     SceneView v; v.tlas = c->d_tlas_nodes; v.objects = c->d_objects; v.blas = c->d_blas_nodes; v.tris = c->d_blas_tris;
     v.wide = c->traversal_mode == PT_TRAVERSAL_WIDE ? c->d_wide : nullptr;
     v.ext_mats = c->d_ext_mats; v.n_ext_mats = c->n_ext_mats; v.pad = 0;
+    v.n_objects = c->n_objects; v.n_tris = (int32_t)std::min<int64_t>(c->n_tris, INT32_MAX);
     return v;
 }
 
@@ -200,7 +201,7 @@ int pt_create(int device_id, pt_ctx** out) {
         delete c; return fail(nullptr, PT_ERR_HIP, "pt_create: hipSetDevice/hipStreamCreate failed");
     }
     c->own_stream = true;
-    c->extend_variant = 2;   // 64-thread workgroups, 16 LDS stack entries (8 waves/SIMD), longer ray class first (tools/extend_ab.py)
+    c->extend_variant = 3;   // 8 waves/SIMD, class of the longest wave first, a tiny scene staged in LDS (tools/extend_ab.py)
     if (const char* v = getenv("PT_EXTEND_VARIANT")) c->extend_variant = atoi(v);
     *out = c;
     return PT_OK;

@@ -23,6 +23,7 @@ struct SceneView {
     const float4* wide;      // fast mode only (pt_set_traversal_mode): compressed 4-wide collapse of the BLAS (PT_WIDE_QUADS per node), else null
     const float4* ext_mats;  // extension materials (pt_material = 2 quads each) for material ids 2.., null by default
     int32_t n_ext_mats, pad;
+    int32_t n_objects, n_tris;   // record counts of the four buffers (the extend kernel stages tiny scenes in LDS)
 };
 
 // PathState (path-tracer.js:131-160) as separate device arrays; vec3f members keep the

@@ -201,7 +201,10 @@ __device__ __forceinline__ void publish(unsigned long long ov, unsigned long lon
 // the slot's own state, the hit is still in registers, and its memory traffic hides under the traversal of the other
 // waves instead of costing a launch.  (The material sample too was tried here: its ~90 registers take the traversal from
 // 8 to 5 waves per SIMD, +30 us per launch; capped at 64 registers it spills, +43 us.  It runs in the compaction launch.)
-template <int LDS_N, int BLOCK, bool COUNT, int ORDER, bool LOG, bool LOGIC, bool WIDE = false>
+// SCENE_QUADS > 0: a scene whose four buffers together fit in SCENE_QUADS quads (12 per object + 7 per triangle) is copied
+// into LDS by every workgroup and traversed from there: the same records, an LDS read instead of an L1 round trip in
+// every link of the trip's dependent chain.
+template <int LDS_N, int BLOCK, bool COUNT, int ORDER, bool LOG, bool LOGIC, bool WIDE = false, int SCENE_QUADS = 0>
 __global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView sc, StepHeader* hdr, const int32_t* __restrict__ cam_q,
                                                         const int32_t* __restrict__ mat_q, int32_t* spill, int64_t spill_stride,
                                                         unsigned long long* wave_log, float* __restrict__ image, uint8_t* __restrict__ code_out,
@@ -216,6 +219,14 @@ __global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView 
     int blk = (ORDER == 2 && hdr->extend_order) ? nblk - 1 - (int)blockIdx.x : (int)blockIdx.x;
     if (blk < 0 || blk >= nblk) return;
     if (LOG && lane_id() == 0) wave_log[4 * (int64_t)(blockIdx.x * (BLOCK >> 6) + (threadIdx.x >> 6)) + 1] = 0;
+    __shared__ float4 s_scene[SCENE_QUADS > 0 ? SCENE_QUADS : 1];
+    if (SCENE_QUADS > 0) {                                       // [tlas | objects | blas | tris]
+        const int m4 = 4 * sc.n_objects, m12 = 12 * sc.n_objects, n4 = 4 * sc.n_tris, total = m12 + 7 * sc.n_tris;
+        for (int i = threadIdx.x; i < total; i += BLOCK)
+            s_scene[i] = i < m4 ? sc.tlas[i] : i < m12 ? sc.objects[i - m4] : i < m12 + n4 ? sc.blas[i - m12] : sc.tris[i - m12 - n4];
+        __syncthreads();
+        sc.tlas = s_scene; sc.objects = s_scene + m4; sc.blas = s_scene + m12; sc.tris = s_scene + m12 + n4;
+    }
     int q = blk * BLOCK + threadIdx.x;
     Ray r; ray_init(r, F3(0, 0, 1), F3(0, 0, 1));
     if (q < n_rays) {
@@ -275,16 +286,16 @@ __global__ __launch_bounds__(PT_BLOCK) void k_extend_direct(SceneView sc, const 
 
 // ---- launchers -------------------------------------------------------------------------------
 static int64_t pad_to(int64_t n, int64_t m) { return (n + m - 1) / m * m; }
-// The spill is sized for the smallest LDS share any variant uses (16 entries) and the largest slot count.
-size_t ptk_spill_ints(int64_t n_rays) { return (size_t)pad_to(n_rays, 256) * (PT_STACK_SIZE - 16); }
+// The spill is sized for the smallest LDS share any variant uses (12 entries) and the largest slot count.
+size_t ptk_spill_ints(int64_t n_rays) { return (size_t)pad_to(n_rays, 256) * (PT_STACK_SIZE - 12); }
 
-template <int LDS_N, int BLOCK, int ORDER, bool WIDE = false>
+template <int LDS_N, int BLOCK, int ORDER, bool WIDE = false, int SCENE_QUADS = 0>
 static void launch_queue(const PathState& ps, int num_paths, const SceneView& sc, StepHeader* hdr, const int32_t* cam_q,
                          const int32_t* mat_q, int32_t* spill, int count, unsigned long long* wave_log, float* image, uint8_t* code, int max_nb,
                          hipStream_t s) {
     int64_t stride = pad_to(num_paths, 256);
     dim3 grid((unsigned)((num_paths + BLOCK - 1) / BLOCK));
-#define PT_LAUNCH(COUNT, LOG, LOGIC) hipLaunchKernelGGL((k_extend_queue<LDS_N, BLOCK, COUNT, ORDER, LOG, LOGIC, WIDE>), grid, dim3(BLOCK), 0, s, ps, sc, hdr, \
+#define PT_LAUNCH(COUNT, LOG, LOGIC) hipLaunchKernelGGL((k_extend_queue<LDS_N, BLOCK, COUNT, ORDER, LOG, LOGIC, WIDE, SCENE_QUADS>), grid, dim3(BLOCK), 0, s, ps, sc, hdr, \
                                                        cam_q, mat_q, spill, stride, wave_log, image, code, max_nb)
     if (wave_log)    PT_LAUNCH(false, true, false);    // measurement replays (code == null): traversal only, idempotent
     else if (!code)  PT_LAUNCH(false, false, false);
@@ -307,19 +318,23 @@ static void launch_queue(const PathState& ps, int num_paths, const SceneView& sc
 // Sensitivity bound: replacing every correctly rounded divide by a bare v_rcp (results no longer exact) gains 7 % on
 // Cornell and 4 % on the 82 k-triangle mesh, so a cheaper exact divide could return at most half of that.
 static const char* kVariantNames[] = {"256-thread workgroups, 24 LDS stack entries", "64-thread workgroups, 16 LDS stack entries",
-                                      "64-thread workgroups, 16 LDS entries, class of the longest wave first"};
-int ptk_extend_num_variants() { return 3; }
-const char* ptk_extend_variant_name(int v) { return (v >= 0 && v < 3) ? kVariantNames[v] : "?"; }
+                                      "64-thread workgroups, 16 LDS entries, class of the longest wave first",
+                                      "as 2; a scene of <= 8 KB is staged in LDS (256-thread workgroups, 12 LDS stack entries)"};
+int ptk_extend_num_variants() { return 4; }
+const char* ptk_extend_variant_name(int v) { return (v >= 0 && v < 4) ? kVariantNames[v] : "?"; }
+#define PT_SCENE_LDS_QUADS 512
 void ptk_extend_queue(const PathState& ps, const RenderConst& rc, const SceneView& sc, StepHeader* hdr, const int32_t* cam_q,
                       const int32_t* mat_q, int32_t* spill, int count, int variant, unsigned long long* wave_log, float* image, uint8_t* code,
                       hipStream_t s) {
     if (sc.wide)           launch_queue<16, 64, 2, true>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rc.max_nb, s);   // fast mode
     else if (variant == 0) launch_queue<24, 256, 1>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rc.max_nb, s);
     else if (variant == 1) launch_queue<16, 64, 1>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rc.max_nb, s);
+    else if (variant == 3 && 12 * (int64_t)sc.n_objects + 7 * (int64_t)sc.n_tris <= PT_SCENE_LDS_QUADS)
+        launch_queue<12, 256, 2, false, PT_SCENE_LDS_QUADS>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rc.max_nb, s);
     else                   launch_queue<16, 64, 2>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rc.max_nb, s);
 }
 int64_t ptk_extend_waves(int num_paths, int variant) {
-    int block = variant == 0 ? 256 : 64;
+    int block = (variant == 0 || variant == 3) ? 256 : 64;   // variant 3 falls back to 64 when the scene does not fit: an upper bound then
     return (int64_t)((num_paths + block - 1) / block) * (block / 64);
 }
 void ptk_extend_direct(const SceneView& sc, const float4* o4, const float4* d4, int n, int32_t* hit_obj, int32_t* hit_tri,

@@ -409,6 +409,29 @@ def test_fast_mode_render(pta, orc, device, built):
     np.testing.assert_allclose(img_e[..., :3], orr.image()[..., :3], rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+def test_every_extend_variant_is_bit_exact(pta, orc, device, built, variant):
+    """The extend kernel's variants (workgroup shape, LDS/HBM stack split, dispatch order, tiny scene staged in LDS) never
+    change a result: whole path state against the oracle after each of 8 steps, on a scene that fits the LDS stage and on
+    one that does not."""
+    import ctypes as C
+    name = C.create_string_buffer(96)
+    assert device.lib.pt_extend_variants(device.ctx, variant, name, 96) == 4 and name.value
+    try:
+        device.call("pt_set_extend_variant", variant)
+        for scene_name, w, h, spp, paths in (("cornell", 64, 36, 8, 3000), ("sphere", 48, 32, 8, 2500)):
+            desc, s, o = built(scene_name)
+            pt = pta.init_path_tracer({"device": device, "scene": s, "image": {"width": w, "height": h}, "camera": desc["camera"],
+                                       "settings": {"samples": spp, "numPaths": paths}})
+            orr = orc.OrcRender(o, w, h, desc["camera"], spp, paths)
+            for step in range(8):
+                gs = pt.step(); cs = orr.step_like_device()
+                assert (gs.n_camera, gs.n_material) == (cs.n_camera, cs.n_material)
+                assert_state_equal(pt, orr, step)
+    finally:
+        device.call("pt_set_extend_variant", 3)
+
+
 def test_error_behaviour(pta, device):
     """Reference: console.warn + undefined (scene.js:149,525); here: negative status + message."""
     dev2 = pta.request_device(0)
