@@ -553,12 +553,23 @@ int pt_path_state_read(pt_ctx* c, const char* field, void* out, size_t bytes) {
     if (!c->render_ready) return fail(c, PT_ERR_STATE, "pt_path_state_read: pt_render_init has not been called");
     HIPOK(c, hipSetDevice(c->device));
     const PathState& ps = c->ps; size_t n = (size_t)c->rc.num_paths; const void* src = nullptr; size_t need = 0;
-    struct { const char* name; const void* p; size_t elem; } tab[] = {
+    struct { const char* name; const void* p; size_t elem; } tab[] = {   // elem 12: a vec3f member, stored packed, returned at 16-byte stride
         {"pixel_index", ps.pixel_index, 4}, {"num_bounces", ps.num_bounces, 4}, {"random_seed", ps.random_seed, 4},
-        {"path_throughput", ps.path_throughput, 16}, {"material_throughput_pdf", ps.material_throughput_pdf, 16},
-        {"path_o", ps.path_o, 16}, {"path_d", ps.path_d, 16}, {"hit_obj", ps.hit_obj, 4}, {"hit_tri", ps.hit_tri, 4},
+        {"path_throughput", ps.path_throughput, 12}, {"material_throughput_pdf", ps.material_throughput_pdf, 16},
+        {"path_o", ps.path_o, 12}, {"path_d", ps.path_d, 12}, {"hit_obj", ps.hit_obj, 4}, {"hit_tri", ps.hit_tri, 4},
         {"flags", ps.flags, 4}, {"samples_in_pixel", ps.samples_in_pixel, 4}};
-    for (auto& t : tab) if (!strcmp(field, t.name)) { src = t.p; need = n * t.elem; }
+    for (auto& t : tab) if (!strcmp(field, t.name)) {
+        if (t.elem == 12) {
+            if (bytes != n * 16) return fail(c, PT_ERR_ARG, "pt_path_state_read: size mismatch");
+            std::vector<float> packed(n * 3);
+            int r = read_back(c, packed.data(), t.p, n * 12);
+            if (r) return r;
+            float* o4 = (float*)out;
+            for (size_t i = 0; i < n; i++) { o4[4 * i] = packed[3 * i]; o4[4 * i + 1] = packed[3 * i + 1]; o4[4 * i + 2] = packed[3 * i + 2]; o4[4 * i + 3] = 0.0f; }
+            return PT_OK;
+        }
+        src = t.p; need = n * t.elem;
+    }
     if (!strcmp(field, "pixel_counter")) { src = &c->d_hdr->pixel_counter; need = 8; }
     if (!src) return fail(c, PT_ERR_ARG, std::string("pt_path_state_read: unknown field ") + field);
     if (bytes != need) return fail(c, PT_ERR_ARG, "pt_path_state_read: size mismatch");

@@ -26,16 +26,18 @@ struct SceneView {
     int32_t n_objects, n_tris;   // record counts of the four buffers (the extend kernel stages tiny scenes in LDS)
 };
 
-// PathState (path-tracer.js:131-160) as separate device arrays; vec3f members keep the
-// reference's 16-byte stride.
+// PathState (path-tracer.js:131-160) as separate device arrays.  The vec3f members are stored as 12-byte records, not
+// at the reference's 16-byte stride: the step streams the whole pool through the caches every iteration, and the pad
+// words were 12 of its 108 bytes per slot (pt_path_state_read hands them back at the reference's stride).
+struct P3 { float x, y, z; };
 struct PathState {
     int32_t*  pixel_index;
     int32_t*  num_bounces;
     float*    random_seed;
-    float4*   path_throughput;
+    P3*       path_throughput;
     float4*   material_throughput_pdf;
-    float4*   path_o;
-    float4*   path_d;
+    P3*       path_o;
+    P3*       path_d;
     int32_t*  hit_obj;
     int32_t*  hit_tri;
     uint32_t* flags;

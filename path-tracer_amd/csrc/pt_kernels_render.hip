@@ -30,7 +30,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_first_logic(PathState ps, RenderCo
     if (i >= rc.num_paths) return;
     uint32_t gi = (uint32_t)(rc.slot_base + i) + rc.seed_mix;              // seed_mix: 0 unless the seed extension is set
     ps.random_seed[i] = (float)base_hash(gi, gi + 1u) * 2.3283064365386962890625e-10f + 0.008f;   // logic.js:77
-    ps.path_throughput[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+    ps.path_throughput[i] = mk3(1.0f, 1.0f, 1.0f);
     code_out[i] = (uint8_t)(PT_CODE_CAMERA | PT_CODE_TICKET);
 }
 

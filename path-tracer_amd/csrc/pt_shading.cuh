@@ -8,6 +8,10 @@
 #define ALBEDO0_POW 0.217637640824031f   // pow(0.5, 2.2): material.js:107 through :72
 #define ALBEDO1_POW 0.0289911870530680f  // pow(0.2, 2.2): material.js:110 through :72
 
+__device__ __forceinline__ f3 F3(P3 v) { return F3(v.x, v.y, v.z); }
+__device__ __forceinline__ P3 mk3(float x, float y, float z) { P3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ P3 mk3(f3 v) { return mk3(v.x, v.y, v.z); }
+
 // code bits: 1 = camera queue, 2 = material queue, 4 = wants a pixel ticket, 8 = finished a sample this step
 #define PT_CODE_CAMERA 1u
 #define PT_CODE_MATERIAL 2u
@@ -33,8 +37,8 @@ __device__ __forceinline__ void generate_one(const PathState& ps, const RenderCo
     f3 fwd = F3(cf.fwd[0], cf.fwd[1], cf.fwd[2]), right = F3(cf.right[0], cf.right[1], cf.right[2]), up = F3(cf.up[0], cf.up[1], cf.up[2]);
     f3 w = normalize3(local);
     f3 d = (right * w.x + fwd * w.y) + up * w.z;
-    ps.path_o[path] = make_float4(pos.x, pos.y, pos.z, 0.0f);
-    ps.path_d[path] = make_float4(d.x, d.y, d.z, 0.0f);
+    ps.path_o[path] = mk3(pos);
+    ps.path_d[path] = mk3(d);
 }
 
 // camera.js:96-111, the part that does not depend on the pixel
@@ -122,8 +126,8 @@ __device__ __forceinline__ void shade_one(const PathState& ps, const SceneView& 
     ps.material_throughput_pdf[path] = bp;
     ps.flags[path] |= flag;
     ps.random_seed[path] = seed;
-    ps.path_o[path] = make_float4(no.x, no.y, no.z, 0.0f);
-    ps.path_d[path] = make_float4(nd.x, nd.y, nd.z, 0.0f);
+    ps.path_o[path] = mk3(no);
+    ps.path_d[path] = mk3(nd);
 }
 
 // ============================================================================================
@@ -159,7 +163,7 @@ __device__ __forceinline__ unsigned logic_one(const PathState& ps, float* __rest
         int sip = ps.samples_in_pixel[i];
         if (sip >= PT_SAMPLES_PER_TICKET - 1) code |= 4u; else ps.samples_in_pixel[i] = sip + 1;
     } else { code |= 2u; nb += 1; }
-    ps.path_throughput[i] = make_float4(tp.x, tp.y, tp.z, 0.0f);
+    ps.path_throughput[i] = mk3(tp);
     ps.num_bounces[i] = nb;
     ps.flags[i] = 0u;
     if (finished) {                                                      // logic.js:145-150
