@@ -110,7 +110,7 @@ int pt_render_reset(pt_ctx* ctx);
  * pt_render_ext, every result is the reference's.  The rules are defined by the oracle (oracle/pt_oracle.h) and reproduced
  * bit for bit by the kernels.  Call after pt_render_init (or pt_render_reset) and before the first step; it survives
  * pt_render_reset.
- *   max_nb     replaces the 20 of logic.js:111 (num_bounces advances by 2 per bounce there); 0 keeps 20
+ *   max_nb     replaces the 20 of logic.js:111 (num_bounces advances by 2 per bounce there); 0 keeps 20; at most 4194304
  *   seed       decorrelates the random streams: added (times 0x9E3779B1 mod 2^32) to the slot index hashed at logic.js:77
  *   materials  materials[k] describes material id k + 2; ids 0 and 1 stay the reference's; an id without an entry keeps the
  *              reference's unknown-id behaviour (zero BRDF)

@@ -398,10 +398,9 @@ int pt_render_init(pt_ctx* c, const pt_render_params* p) {
     c->ticket_begin = p->ticket_end >= 0 ? p->ticket_begin : 0;
     int r; size_t n = (size_t)np;
     PathState& ps = c->ps;   // zero-filled like a new GPUBuffer (path-tracer.js:271-275)
-    if ((r = ralloc(c, &ps.pixel_index, n)) || (r = ralloc(c, &ps.num_bounces, n)) || (r = ralloc(c, &ps.random_seed, n)) ||
+    if ((r = ralloc(c, &ps.pixel_index, n)) || (r = ralloc(c, &ps.state, n)) || (r = ralloc(c, &ps.random_seed, n)) ||
         (r = ralloc(c, &ps.path_throughput, n)) || (r = ralloc(c, &ps.material_throughput_pdf, n)) || (r = ralloc(c, &ps.path_o, n)) ||
-        (r = ralloc(c, &ps.path_d, n)) || (r = ralloc(c, &ps.hit_obj, n)) || (r = ralloc(c, &ps.hit_tri, n)) || (r = ralloc(c, &ps.flags, n)) ||
-        (r = ralloc(c, &ps.samples_in_pixel, n)) || (r = ralloc(c, &ps.ticket_acc, n)))
+        (r = ralloc(c, &ps.path_d, n)) || (r = ralloc(c, &ps.hit, n)) || (r = ralloc(c, &ps.ticket_acc, n)))
         return r;
     c->nblocks = ptk_step_blocks((int)np);
     if ((r = ralloc(c, &c->d_code, (size_t)c->nblocks * PT_STEP_BLOCK)) || (r = ralloc(c, &c->d_blk_counts, (size_t)c->nblocks)) ||
@@ -427,7 +426,7 @@ int pt_render_set_extensions(pt_ctx* c, const pt_render_ext* e) {
     if (!c || !e) return fail(c, PT_ERR_ARG, "pt_render_set_extensions: null argument");
     if (!c->render_ready) return fail(c, PT_ERR_STATE, "pt_render_set_extensions: pt_render_init has not been called");
     if (c->step != 0) return fail(c, PT_ERR_STATE, "pt_render_set_extensions: the render has started; call pt_render_reset first");
-    if (e->max_nb < 0 || e->n_materials < 0 || e->n_materials > PT_MAX_EXT_MATERIALS) return fail(c, PT_ERR_ARG, "pt_render_set_extensions: bad max_nb or n_materials");
+    if (e->max_nb < 0 || e->max_nb > PT_MAX_NB_LIMIT || e->n_materials < 0 || e->n_materials > PT_MAX_EXT_MATERIALS) return fail(c, PT_ERR_ARG, "pt_render_set_extensions: bad max_nb or n_materials");
     for (int k = 0; k < e->n_materials; k++)
         if (e->materials[k].type < 0 || e->materials[k].type > PT_MAT_MIRROR) return fail(c, PT_ERR_ARG, "pt_render_set_extensions: unknown material type");
     HIPOK(c, hipSetDevice(c->device));
@@ -553,11 +552,24 @@ int pt_path_state_read(pt_ctx* c, const char* field, void* out, size_t bytes) {
     if (!c->render_ready) return fail(c, PT_ERR_STATE, "pt_path_state_read: pt_render_init has not been called");
     HIPOK(c, hipSetDevice(c->device));
     const PathState& ps = c->ps; size_t n = (size_t)c->rc.num_paths; const void* src = nullptr; size_t need = 0;
+    {   // members the device keeps packed (pt_internal.h PathState): unpacked into the reference's i32 / u32 arrays
+        const bool nb = !strcmp(field, "num_bounces"), fl = !strcmp(field, "flags"), sip = !strcmp(field, "samples_in_pixel");
+        const bool ho = !strcmp(field, "hit_obj"), ht = !strcmp(field, "hit_tri");
+        if (nb || fl || sip || ho || ht) {
+            if (bytes != n * 4) return fail(c, PT_ERR_ARG, "pt_path_state_read: size mismatch");
+            std::vector<uint32_t> raw(n * ((ho || ht) ? 2 : 1));
+            int r = read_back(c, raw.data(), (ho || ht) ? (const void*)ps.hit : (const void*)ps.state, raw.size() * 4);
+            if (r) return r;
+            uint32_t* o = (uint32_t*)out;
+            for (size_t i = 0; i < n; i++)
+                o[i] = ho ? raw[2 * i] : ht ? raw[2 * i + 1] : nb ? PT_ST_NB(raw[i]) : sip ? PT_ST_SIP(raw[i]) : (raw[i] & (PT_ST_RETIRED | 3u));
+            return PT_OK;
+        }
+    }
     struct { const char* name; const void* p; size_t elem; } tab[] = {   // elem 12: a vec3f member, stored packed, returned at 16-byte stride
-        {"pixel_index", ps.pixel_index, 4}, {"num_bounces", ps.num_bounces, 4}, {"random_seed", ps.random_seed, 4},
+        {"pixel_index", ps.pixel_index, 4}, {"random_seed", ps.random_seed, 4},
         {"path_throughput", ps.path_throughput, 12}, {"material_throughput_pdf", ps.material_throughput_pdf, 16},
-        {"path_o", ps.path_o, 12}, {"path_d", ps.path_d, 12}, {"hit_obj", ps.hit_obj, 4}, {"hit_tri", ps.hit_tri, 4},
-        {"flags", ps.flags, 4}, {"samples_in_pixel", ps.samples_in_pixel, 4}};
+        {"path_o", ps.path_o, 12}, {"path_d", ps.path_d, 12}};
     for (auto& t : tab) if (!strcmp(field, t.name)) {
         if (t.elem == 12) {
             if (bytes != n * 16) return fail(c, PT_ERR_ARG, "pt_path_state_read: size mismatch");

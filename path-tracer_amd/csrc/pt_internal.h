@@ -29,19 +29,24 @@ struct SceneView {
 // PathState (path-tracer.js:131-160) as separate device arrays.  The vec3f members are stored as 12-byte records, not
 // at the reference's 16-byte stride: the step streams the whole pool through the caches every iteration, and the pad
 // words were 12 of its 108 bytes per slot (pt_path_state_read hands them back at the reference's stride).
+// num_bounces, samples_in_pixel and flags share one word per slot (PT_ST_*): the logic pass reads and writes all three
+// every step, and one load + one store replace three of each.  hit_obj / hit_tri are one int2 for the same reason.
 struct P3 { float x, y, z; };
+#define PT_ST_RETIRED 0x80000000u                                  // flags bit 31 (logic.js:72,179)
+#define PT_ST_FLAGS(s) ((s) & 3u)                                  // flags bits 0-1 (material.js:118; bit 1: emitter extension)
+#define PT_ST_SIP(s) (((s) >> 2) & 7u)                             // samples_in_pixel, 0..7 (logic.js:129-133)
+#define PT_ST_NB(s) (((s) >> 8) & 0x7fffffu)                       // num_bounces (<= max_nb + 2; pt_render_set_extensions bounds max_nb)
+#define PT_ST_PACK(flags, sip, nb) ((uint32_t)(flags) | ((uint32_t)(sip) << 2) | ((uint32_t)(nb) << 8))
+#define PT_MAX_NB_LIMIT (1 << 22)
 struct PathState {
     int32_t*  pixel_index;
-    int32_t*  num_bounces;
+    uint32_t* state;             // PT_ST_*: flags | samples_in_pixel | num_bounces
     float*    random_seed;
     P3*       path_throughput;
     float4*   material_throughput_pdf;
     P3*       path_o;
     P3*       path_d;
-    int32_t*  hit_obj;
-    int32_t*  hit_tri;
-    uint32_t* flags;
-    int32_t*  samples_in_pixel;
+    int2*     hit;               // {hit_obj, hit_tri}
     float4*   ticket_acc;        // not in the reference: radiance sum + sample count of the slot's current pixel ticket
 };
 

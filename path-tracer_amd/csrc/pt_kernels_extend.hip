@@ -235,7 +235,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView 
         Stack<LDS_N, BLOCK> stk{s_stack + threadIdx.x, spill + q, spill_stride};
         while (trav_step<COUNT, Stack<LDS_N, BLOCK>, WIDE>(sc, r, stk)) {}
         trav_finish<COUNT>(sc, r);
-        ps.hit_obj[path] = r.hit_obj; ps.hit_tri[path] = r.hit_tri;
+        ps.hit[path] = make_int2(r.hit_obj, r.hit_tri);
         if (LOGIC) {
             unsigned code = logic_one(ps, image, path, r.hit_obj >= 0, max_nb);
             code_out[path] = (uint8_t)code;

@@ -122,14 +122,14 @@ __global__ __launch_bounds__(PT_BLOCK) void k_compact_generate_shade(PathState p
     if (code & 2u) mat_q[off.y + rank_below(b_mat)] = i;
     if (code & 4u) {
         int64_t ticket = ticket_base + off.z + rank_below(b_tix);
-        if (ticket >= rc.ticket_limit) ps.flags[i] |= (1u << 31);                  // logic.js:177-179
+        if (ticket >= rc.ticket_limit) ps.state[i] |= PT_ST_RETIRED;                // logic.js:177-179
         else {                                                                      // logic.js:181-182
             ps.pixel_index[i] = (int32_t)(ticket % ((int64_t)rc.width * rc.height));
-            ps.samples_in_pixel[i] = 0;
+            ps.state[i] &= ~(7u << 2);                                              // samples_in_pixel = 0
         }
     }
     if (code & 1u) generate_one(ps, rc, i);
-    if (code & 2u) shade_one(ps, sc, i, ps.hit_obj[i], ps.hit_tri[i]);
+    if (code & 2u) { int2 h = ps.hit[i]; shade_one(ps, sc, i, h.x, h.y); }
 }
 
 // Adds the unfinished tickets' partial sums to the image (and clears them) so that a host looking at the image in

@@ -124,7 +124,7 @@ __device__ __forceinline__ void shade_one(const PathState& ps, const SceneView& 
     }
     f3 no = hit_pos + n * 0.0001f;
     ps.material_throughput_pdf[path] = bp;
-    ps.flags[path] |= flag;
+    ps.state[path] |= flag;
     ps.random_seed[path] = seed;
     ps.path_o[path] = mk3(no);
     ps.path_d[path] = mk3(nd);
@@ -139,10 +139,11 @@ __device__ __forceinline__ void shade_one(const PathState& ps, const SceneView& 
 // ============================================================================================
 __device__ __forceinline__ unsigned logic_one(const PathState& ps, float* __restrict__ image, int i, bool b_hit, int max_nb) {
     unsigned code = 0; bool finished = false;
-    if ((ps.flags[i] & (1u << 31)) != 0u) return 0u;                             // logic.js:66 a slot past the last ticket
+    const uint32_t st = ps.state[i];
+    if ((st & PT_ST_RETIRED) != 0u) return 0u;                                   // logic.js:66 a slot past the last ticket
     f3  tp = F3(ps.path_throughput[i]);
-    int nb = ps.num_bounces[i] + 1;
-    uint32_t flags = ps.flags[i];
+    int nb = (int)PT_ST_NB(st) + 1, sip = (int)PT_ST_SIP(st);
+    uint32_t flags = PT_ST_FLAGS(st);
     f3 contrib = F3(0.0f, 0.0f, 0.0f);
     if (flags & 2u) {                                                   // extension: the ray hit an emitter (pt_amd.h pt_material)
         contrib = tp * F3(ps.material_throughput_pdf[i]); tp = F3(0.0f, 0.0f, 0.0f);
@@ -160,12 +161,10 @@ __device__ __forceinline__ unsigned logic_one(const PathState& ps, float* __rest
     if (!b_hit) { contrib = F3(contrib.x + 2.0f * tp.x, contrib.y + 2.0f * tp.y, contrib.z + 2.0f * tp.z); tp = F3(0.0f, 0.0f, 0.0f); }
     if (tp.x == 0.0f && tp.y == 0.0f && tp.z == 0.0f) {                  // logic.js:121-133
         finished = true; code |= 1u; nb = 0; tp = F3(1.0f, 1.0f, 1.0f);
-        int sip = ps.samples_in_pixel[i];
-        if (sip >= PT_SAMPLES_PER_TICKET - 1) code |= 4u; else ps.samples_in_pixel[i] = sip + 1;
+        if (sip >= PT_SAMPLES_PER_TICKET - 1) code |= 4u; else sip += 1;
     } else { code |= 2u; nb += 1; }
     ps.path_throughput[i] = mk3(tp);
-    ps.num_bounces[i] = nb;
-    ps.flags[i] = 0u;
+    ps.state[i] = PT_ST_PACK(0u, sip, nb);                               // flags = 0 (logic.js:142)
     if (finished) {                                                      // logic.js:145-150
         float4 acc = ps.ticket_acc[i];
         acc.x += contrib.x; acc.y += contrib.y; acc.z += contrib.z; acc.w += 1.0f;
