@@ -67,6 +67,7 @@ SIGNATURES = {
     "pt_get_objects": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "pt_get_tlas_perm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "pt_get_mesh_perm": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
+    "pt_scene_get_stack_bound": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "pt_trace_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pt_render_init": (C.c_int, [C.c_void_p, C.POINTER(PtRenderParams)]),
     "pt_render_reset": (C.c_int, [C.c_void_p]),

@@ -32,7 +32,7 @@ struct pt_ctx {
     int device = 0; int extend_variant = 0; hipStream_t stream = nullptr; bool own_stream = false; std::string err;
     std::vector<Mesh> meshes;
     // scene
-    bool scene_built = false; int64_t n_tris = 0; int n_objects = 0; int n_meshes_used = 0;
+    bool scene_built = false; int64_t n_tris = 0; int n_objects = 0; int n_meshes_used = 0; int32_t stack_bound = INT32_MAX;
     float4 *d_blas_nodes = nullptr, *d_blas_tris = nullptr, *d_tlas_nodes = nullptr, *d_objects = nullptr;
     int32_t* d_tlas_perm = nullptr;
     // render
@@ -77,10 +77,42 @@ struct Tmp {
     }
 };
 
+int read_back(pt_ctx* c, void* dst, const void* src, size_t bytes);
+
+// Most stack entries a ray can hold at once: every entry is the far child of an inner node on the path from the root to
+// the node being visited (TLAS part below switch_pt, BLAS part above it), so the bound is the number of inner nodes on the
+// longest root-to-leaf path of the TLAS plus that of the deepest BLAS.  Only evaluated (on the host, from the built nodes)
+// for scenes small enough for the LDS-staged extend variant, whose kernel then drops the spill path and the overflow guard.
+// A tree the walk cannot finish on (the degenerate one-primitive tree can point at itself) leaves the bound unknown.
+int tree_path_inner_nodes(const std::vector<pt_bvh_node>& nodes, int64_t first, int64_t count, int64_t root) {
+    std::vector<std::pair<int64_t, int>> todo{{root, 1}};
+    int best = 0; int64_t visits = 0;
+    while (!todo.empty()) {
+        auto [n, depth] = todo.back(); todo.pop_back();
+        if (n < first || n >= first + count || ++visits > count) return INT32_MAX;
+        best = std::max(best, depth);
+        if (nodes[(size_t)n].l_child >= 0) todo.push_back({nodes[(size_t)n].l_child, depth + 1});
+        if (nodes[(size_t)n].r_child >= 0) todo.push_back({nodes[(size_t)n].r_child, depth + 1});
+    }
+    return best;
+}
+int scene_stack_bound(pt_ctx* c) {
+    c->stack_bound = INT32_MAX;
+    if (12 * (int64_t)c->n_objects + 7 * c->n_tris > PT_SCENE_LDS_QUADS) return PT_OK;
+    std::vector<pt_bvh_node> tlas((size_t)c->n_objects), blas((size_t)c->n_tris); std::vector<pt_object> objs((size_t)c->n_objects);
+    int r;
+    if ((r = read_back(c, tlas.data(), c->d_tlas_nodes, tlas.size() * sizeof(pt_bvh_node))) || (r = read_back(c, blas.data(), c->d_blas_nodes, blas.size() * sizeof(pt_bvh_node))) ||
+        (r = read_back(c, objs.data(), c->d_objects, objs.size() * sizeof(pt_object)))) return r;
+    int64_t bound = tree_path_inner_nodes(tlas, 0, c->n_objects, 0), deepest = 0;
+    for (const pt_object& o : objs) deepest = std::max<int64_t>(deepest, tree_path_inner_nodes(blas, 0, c->n_tris, o.bvh_offset));
+    c->stack_bound = (int32_t)std::min<int64_t>(bound + deepest, INT32_MAX);
+    return PT_OK;
+}
+
 SceneView scene_view(const pt_ctx* c) {
     SceneView v; v.tlas = c->d_tlas_nodes; v.objects = c->d_objects; v.blas = c->d_blas_nodes; v.tris = c->d_blas_tris;
     v.wide = c->traversal_mode == PT_TRAVERSAL_WIDE ? c->d_wide : nullptr;
-    v.ext_mats = c->d_ext_mats; v.n_ext_mats = c->n_ext_mats; v.pad = 0;
+    v.ext_mats = c->d_ext_mats; v.n_ext_mats = c->n_ext_mats; v.stack_bound = c->stack_bound;
     v.n_objects = c->n_objects; v.n_tris = (int32_t)std::min<int64_t>(c->n_tris, INT32_MAX);
     return v;
 }
@@ -302,6 +334,7 @@ int pt_scene_build(pt_ctx* c, const pt_instance* inst, int n_inst) {
     HIPOK(c, hipGetLastError());
     HIPOK(c, hipStreamSynchronize(c->stream));
     c->scene_built = true;
+    if ((rc = scene_stack_bound(c))) return rc;
     return c->traversal_mode == PT_TRAVERSAL_WIDE ? build_wide(c) : PT_OK;
 }
 
@@ -334,6 +367,12 @@ SCENE_GETTER(pt_get_tlas_nodes, pt_bvh_node, c->d_tlas_nodes, c->n_objects)
 SCENE_GETTER(pt_get_objects, pt_object, c->d_objects, c->n_objects)
 SCENE_GETTER(pt_get_tlas_perm, int32_t, c->d_tlas_perm, c->n_objects)
 
+int pt_scene_get_stack_bound(pt_ctx* c, int32_t* bound) {
+    if (!c || !bound) return fail(c, PT_ERR_ARG, "pt_scene_get_stack_bound: null argument");
+    if (!c->scene_built) return fail(c, PT_ERR_STATE, "scene has not been built yet");
+    *bound = c->stack_bound;
+    return PT_OK;
+}
 int pt_get_mesh_perm(pt_ctx* c, int mesh, int32_t* out, int64_t n) {
     if (!c || !out) return fail(c, PT_ERR_ARG, "pt_get_mesh_perm: null argument");
     if (mesh < 0 || mesh >= (int)c->meshes.size() || !c->meshes[mesh].built) return fail(c, PT_ERR_STATE, "pt_get_mesh_perm: mesh not built");

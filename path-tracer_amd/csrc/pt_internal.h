@@ -9,6 +9,8 @@
 #define PT_STACK_SIZE 64             // traversal stack entries per ray (reference: 32, scene.js:305)
 #define PT_LDS_STACK 24              // pt_trace_rays (256-thread workgroups): the first PT_LDS_STACK entries live in LDS, the rest
                                      // in an HBM spill; the render's extend variants choose their own split (pt_kernels_extend.hip)
+#define PT_SCENE_LDS_QUADS 512       // a scene of at most this many 16-B quads (12 per object + 7 per triangle) is staged in LDS
+#define PT_STAGED_LDS_STACK 12       // LDS stack entries per ray of the staged extend variant
 #define PT_MAX_ITERS (1 << 20)       // traversal loop guard (degenerate N=1 trees can self-loop)
 #define PT_SAMPLES_PER_TICKET 8      // logic.js:6 SAMPLES_PER_PIXEL_PER_PATH
 
@@ -22,7 +24,9 @@ struct SceneView {
     const float4* tris;      // pt_triangle[n_tris]
     const float4* wide;      // fast mode only (pt_set_traversal_mode): compressed 4-wide collapse of the BLAS (PT_WIDE_QUADS per node), else null
     const float4* ext_mats;  // extension materials (pt_material = 2 quads each) for material ids 2.., null by default
-    int32_t n_ext_mats, pad;
+    int32_t n_ext_mats;
+    int32_t stack_bound;         // most stack entries any ray can hold in this scene (TLAS depth + deepest BLAS depth), or
+                                 // INT32_MAX when unknown: only computed for scenes small enough to be staged in LDS
     int32_t n_objects, n_tris;   // record counts of the four buffers (the extend kernel stages tiny scenes in LDS)
 };
 

@@ -16,15 +16,19 @@ __device__ __forceinline__ int rank_below(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
 }
 
-template <int LDS_N, int BLOCK>
+// SHALLOW: the host has checked that no ray's stack can exceed LDS_N entries in this scene (TLAS depth + deepest BLAS
+// depth, pt_api.hip scene_stack_bound), so neither the spill nor the overflow guard is compiled in.
+template <int LDS_N, int BLOCK, bool SHALLOW = false>
 struct Stack {
+    static constexpr bool shallow = SHALLOW;
     int* lds;            // &s_stack[0][thread]
     int32_t* spill;      // &spill[0][slot]
     int64_t stride;      // slots per spill entry
     __device__ __forceinline__ void put(int sp, int v) const {
-        if (sp < LDS_N) lds[sp * BLOCK] = v; else spill[(int64_t)(sp - LDS_N) * stride] = v;
+        if (SHALLOW || sp < LDS_N) lds[sp * BLOCK] = v; else spill[(int64_t)(sp - LDS_N) * stride] = v;
     }
     __device__ __forceinline__ int get(int sp) const {
+        if (SHALLOW) return lds[(sp < 0 ? 0 : sp) * BLOCK];          // sp = -1 ends the loop; the value read is not used
         return sp < 0 ? 0 : (sp < LDS_N ? lds[sp * BLOCK] : spill[(int64_t)(sp - LDS_N) * stride]);
     }
 };
@@ -153,14 +157,17 @@ __device__ __forceinline__ bool trav_step(const SceneView& sc, Ray& r, const STK
         bool l_valid = l_dist != -1e30f && l_dist < r.hit_dist;
         bool r_valid = r_dist != -1e30f && r_dist < r.hit_dist;
         int l_child = __float_as_int(q0.w), r_child = __float_as_int(q2.w);
-        if (l_valid && r_valid) {
-            bool l_first = l_dist < r_dist;
-            if (r.sp >= PT_STACK_SIZE) { r.overflow = 1; return false; }
-            stk.put(r.sp, l_first ? r_child : l_child);
-            r.sp += 1; r.node = l_first ? l_child : r_child;
-        } else if (l_valid) r.node = l_child;
-        else if (r_valid)   r.node = r_child;
-        else { r.sp -= 1; r.node = stk.get(r.sp); }
+        // one select for the child to visit, one guarded push, one guarded pop (fewer exec-mask manipulations than the
+        // reference's four-way if / else chain; same outcome in every case)
+        const bool both = l_valid && r_valid;
+        const bool take_l = l_valid && (!r_valid || l_dist < r_dist);
+        if (both) {
+            if (!STK::shallow && r.sp >= PT_STACK_SIZE) { r.overflow = 1; return false; }
+            stk.put(r.sp, take_l ? r_child : l_child);
+            r.sp += 1;
+        }
+        r.node = take_l ? l_child : r_child;
+        if (!(l_valid || r_valid)) { r.sp -= 1; r.node = stk.get(r.sp); }
     }
     return r.sp >= 0;
 }
@@ -204,7 +211,7 @@ __device__ __forceinline__ void publish(unsigned long long ov, unsigned long lon
 // SCENE_QUADS > 0: a scene whose four buffers together fit in SCENE_QUADS quads (12 per object + 7 per triangle) is copied
 // into LDS by every workgroup and traversed from there: the same records, an LDS read instead of an L1 round trip in
 // every link of the trip's dependent chain.
-template <int LDS_N, int BLOCK, bool COUNT, int ORDER, bool LOG, bool LOGIC, bool WIDE = false, int SCENE_QUADS = 0>
+template <int LDS_N, int BLOCK, bool COUNT, int ORDER, bool LOG, bool LOGIC, bool WIDE = false, int SCENE_QUADS = 0, bool SHALLOW = false>
 __global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView sc, StepHeader* hdr, const int32_t* __restrict__ cam_q,
                                                         const int32_t* __restrict__ mat_q, int32_t* spill, int64_t spill_stride,
                                                         unsigned long long* wave_log, float* __restrict__ image, uint8_t* __restrict__ code_out,
@@ -232,8 +239,9 @@ __global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView 
     if (q < n_rays) {
         int path = q < n_cam ? cam_q[q] : mat_q[q - n_cam];
         ray_init(r, F3(ps.path_o[path]), F3(ps.path_d[path]));
-        Stack<LDS_N, BLOCK> stk{s_stack + threadIdx.x, spill + q, spill_stride};
-        while (trav_step<COUNT, Stack<LDS_N, BLOCK>, WIDE>(sc, r, stk)) {}
+        typedef Stack<LDS_N, BLOCK, SHALLOW> STK;
+        STK stk{s_stack + threadIdx.x, spill + q, spill_stride};
+        while (trav_step<COUNT, STK, WIDE>(sc, r, stk)) {}
         trav_finish<COUNT>(sc, r);
         ps.hit[path] = make_int2(r.hit_obj, r.hit_tri);
         if (LOGIC) {
@@ -287,15 +295,15 @@ __global__ __launch_bounds__(PT_BLOCK) void k_extend_direct(SceneView sc, const 
 // ---- launchers -------------------------------------------------------------------------------
 static int64_t pad_to(int64_t n, int64_t m) { return (n + m - 1) / m * m; }
 // The spill is sized for the smallest LDS share any variant uses (12 entries) and the largest slot count.
-size_t ptk_spill_ints(int64_t n_rays) { return (size_t)pad_to(n_rays, 256) * (PT_STACK_SIZE - 12); }
+size_t ptk_spill_ints(int64_t n_rays) { return (size_t)pad_to(n_rays, 256) * (PT_STACK_SIZE - PT_STAGED_LDS_STACK); }
 
-template <int LDS_N, int BLOCK, int ORDER, bool WIDE = false, int SCENE_QUADS = 0>
+template <int LDS_N, int BLOCK, int ORDER, bool WIDE = false, int SCENE_QUADS = 0, bool SHALLOW = false>
 static void launch_queue(const PathState& ps, int num_paths, const SceneView& sc, StepHeader* hdr, const int32_t* cam_q,
                          const int32_t* mat_q, int32_t* spill, int count, unsigned long long* wave_log, float* image, uint8_t* code, int max_nb,
                          hipStream_t s) {
     int64_t stride = pad_to(num_paths, 256);
     dim3 grid((unsigned)((num_paths + BLOCK - 1) / BLOCK));
-#define PT_LAUNCH(COUNT, LOG, LOGIC) hipLaunchKernelGGL((k_extend_queue<LDS_N, BLOCK, COUNT, ORDER, LOG, LOGIC, WIDE, SCENE_QUADS>), grid, dim3(BLOCK), 0, s, ps, sc, hdr, \
+#define PT_LAUNCH(COUNT, LOG, LOGIC) hipLaunchKernelGGL((k_extend_queue<LDS_N, BLOCK, COUNT, ORDER, LOG, LOGIC, WIDE, SCENE_QUADS, SHALLOW>), grid, dim3(BLOCK), 0, s, ps, sc, hdr, \
                                                        cam_q, mat_q, spill, stride, wave_log, image, code, max_nb)
     if (wave_log)    PT_LAUNCH(false, true, false);    // measurement replays (code == null): traversal only, idempotent
     else if (!code)  PT_LAUNCH(false, false, false);
@@ -322,15 +330,18 @@ static const char* kVariantNames[] = {"256-thread workgroups, 24 LDS stack entri
                                       "as 2; a scene of <= 8 KB is staged in LDS (256-thread workgroups, 12 LDS stack entries)"};
 int ptk_extend_num_variants() { return 4; }
 const char* ptk_extend_variant_name(int v) { return (v >= 0 && v < 4) ? kVariantNames[v] : "?"; }
-#define PT_SCENE_LDS_QUADS 512
 void ptk_extend_queue(const PathState& ps, const RenderConst& rc, const SceneView& sc, StepHeader* hdr, const int32_t* cam_q,
                       const int32_t* mat_q, int32_t* spill, int count, int variant, unsigned long long* wave_log, float* image, uint8_t* code,
                       hipStream_t s) {
     if (sc.wide)           launch_queue<16, 64, 2, true>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rc.max_nb, s);   // fast mode
     else if (variant == 0) launch_queue<24, 256, 1>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rc.max_nb, s);
     else if (variant == 1) launch_queue<16, 64, 1>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rc.max_nb, s);
-    else if (variant == 3 && 12 * (int64_t)sc.n_objects + 7 * (int64_t)sc.n_tris <= PT_SCENE_LDS_QUADS)
-        launch_queue<12, 256, 2, false, PT_SCENE_LDS_QUADS>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rc.max_nb, s);
+    else if (variant == 3 && 12 * (int64_t)sc.n_objects + 7 * (int64_t)sc.n_tris <= PT_SCENE_LDS_QUADS) {
+        if (sc.stack_bound <= PT_STAGED_LDS_STACK)      // no ray's stack can leave LDS: no spill path, no overflow guard
+            launch_queue<PT_STAGED_LDS_STACK, 256, 2, false, PT_SCENE_LDS_QUADS, true>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rc.max_nb, s);
+        else
+            launch_queue<PT_STAGED_LDS_STACK, 256, 2, false, PT_SCENE_LDS_QUADS>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rc.max_nb, s);
+    }
     else                   launch_queue<16, 64, 2>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rc.max_nb, s);
 }
 int64_t ptk_extend_waves(int num_paths, int variant) {

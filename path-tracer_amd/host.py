@@ -227,6 +227,11 @@ class Scene:
         self.device.call("pt_scene_get_info", C.byref(inf))
         return inf
 
+    def stack_bound(self):
+        b = C.c_int32()
+        self.device.call("pt_scene_get_stack_bound", C.byref(b))
+        return b.value
+
     def _get(self, name, n, dtype, cols):
         out = np.empty((n, cols), dtype=dtype)
         self.device.call(name, out.ctypes.data_as(C.c_void_p), n)

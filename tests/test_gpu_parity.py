@@ -515,3 +515,45 @@ def test_deep_stack_uses_the_hbm_spill(pta, orc, device):
         np.testing.assert_array_equal(pt.field("hit_tri"), orr.field("hit_tri"))
     rs = pt.run(max_steps=2, count_bytes=True)
     assert rs.stack_overflows == 0 and rs.traversal_bytes > 256 * 64 * 100_000
+
+
+def test_staged_scene_stack_bound(pta, orc, device, built):
+    """A scene small enough for the LDS stage gets a stack bound from the built trees.  The Cornell box is shallow (its
+    staged kernel has no spill path and no overflow guard: that is what every Cornell test above runs) and no oracle ray
+    ever holds more entries than the bound; a 31-triangle mesh whose Morton codes are 0 and the thirty single bits builds
+    a chain as deep as the code is long, is over the bound of the LDS stack, and takes the staged kernel with the spill
+    path -- both bit-exact against the oracle, whole path state after every step."""
+    desc, s, o = built("cornell")
+    assert 0 < s.stack_bound() <= 12
+    ro, rd = rays_for(desc, 20000, 5)
+    o.trace_rays(ro, rd, counts=True)
+    assert o.last_max_depth <= s.stack_bound()
+    assert built("sphere")[1].stack_bound() == 2**31 - 1             # too large to stage: not evaluated
+    pos = [np.zeros(3)]
+    for axis in range(3):
+        for j in range(10):
+            p = np.zeros(3); p[axis] = (2.0 ** j + 0.5) / 1024.0; pos.append(p)
+    pos = np.asarray(pos)
+    eps = 1e-4
+    tri = np.array([[-eps, -eps, 0], [eps, -eps, 0], [0, eps, 0]])
+    v = (pos[:, None, :] + tri[None]).reshape(-1, 3).astype(np.float32)
+    mesh = pta.scenes.mesh_from_vertices(v, np.arange(len(v)).reshape(-1, 3))
+    cam = {"position": [-1.0, 0.2, 0.3], "lookAt": [0.3, 0.0, 0.0], "fov": 40.0}
+    # two instances: a one-instance TLAS is the degenerate tree whose right child is the node itself, for which no bound exists
+    cdesc = {"meshes": [mesh], "instances": [(0, [0, 0, 0], [0, 0, 0], [1, 1, 1], 0), (0, [0.1, 0.3, -0.2], [0.2, 0.1, 0.4], [1, 1, 1], 1)], "camera": cam}
+    assert built("floor")[1].stack_bound() == 2**31 - 1              # one instance: unknown, the guarded kernel runs
+    dev2 = pta.request_device(0)
+    try:
+        cs = pta.scenes.populate(pta.init_scene(dev2), cdesc); cs.build()
+        co = orc.OrcScene(cdesc)
+        np.testing.assert_array_equal(cs.blas_nodes()[:, NODE_COLS], co.blas_nodes()[:, NODE_COLS])
+        assert 12 < cs.stack_bound() <= 31, cs.stack_bound()
+        w, h, spp, paths = 48, 32, 8, 2000
+        pt = pta.init_path_tracer({"device": dev2, "scene": cs, "image": {"width": w, "height": h}, "camera": cam, "settings": {"samples": spp, "numPaths": paths}})
+        orr = orc.OrcRender(co, w, h, cam, spp, paths)
+        for step in range(6):
+            gs = pt.step(); c_ = orr.step_like_device()
+            assert (gs.n_camera, gs.n_material) == (c_.n_camera, c_.n_material)
+            assert_state_equal(pt, orr, step)
+    finally:
+        dev2.destroy()
