@@ -4,9 +4,9 @@
     python bench.py --gpus N --steps K --warmup W
 
 Metric (BASELINE.json): Mrays/s at 1920x1080.  Workload at N=1: configs[1], the Cornell box at 1920x1080,
-64 spp, 1,000,000 path slots (the reference's NUM_PATHS).  One "step" = one complete render of that frame:
-every wavefront iteration (logic -> scan -> compact -> generate -> shade -> extend) until both stage-2 queues
-are empty, with the scene and all buffers already resident in HBM.  N > 1: one process per GPU (torchrun),
+64 spp, 2,000,000 path slots in flight (--paths; the reference hard-codes NUM_PATHS = 1,000,000).  One "step" = one
+complete render of that frame: every wavefront iteration (count -> compact+generate+shade -> extend+logic) until both
+stage-2 queues are empty, with the scene and all buffers already resident in HBM.  N > 1: one process per GPU (torchrun),
 each GPU renders the full 64 spp with its own RNG streams (slot_base = rank * NUM_PATHS) and its own ticket
 range, i.e. the node accumulates N*64 spp ("weak": per-GPU work fixed); the per-GPU accumulation buffers are
 combined by one RCCL sum-reduce to rank 0 inside the timed region of every step.
@@ -175,13 +175,14 @@ def main():
 
 
 def pmc_traffic(config):
-    """HBM-side read bytes per extend launch from the committed rocprofv3 PMC pass of this same command
-    (profiles/traffic_<config>.json, written by tools/pmc_traffic.py from TCC_EA0_RDREQ{,_32B,_128B}); None if absent.
+    """HBM-side bytes (reads + writes) per extend launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/traffic_<config>.json, written by tools/pmc_traffic.py from TCC_EA0_RDREQ{,_32B,_128B} and WRITE_SIZE); None if absent.
     PMC counters cannot be collected from inside the timed run, so this is the profiled run's figure."""
     f = os.path.join(ROOT, "profiles", f"traffic_{config}.json")
     if not os.path.exists(f):
         return None
-    return json.load(open(f)).get("hbm_read_bytes_per_launch")
+    t = json.load(open(f))
+    return t.get("hbm_bytes_per_launch", t.get("hbm_read_bytes_per_launch"))
 
 
 def cpu_baseline(pta, desc, w, h, spp, paths):

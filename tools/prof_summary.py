@@ -24,7 +24,7 @@ def main():
         q = ("select kernel_name, counter_name, count(*), sum(value) from counters_collection "
              "group by kernel_name, counter_name order by kernel_name, counter_name")
         for kname, cname, n, tot in cur.execute(q):
-            print(f"{short(kname):<60}{cname:<28}{n:>8}{tot:>22.1f}{tot / n:>18.1f}")
+            print(f"{short(kname):<72} {cname:<28}{n:>8}{tot:>22.1f}{tot / n:>18.1f}")
 
 
 if __name__ == "__main__":
