@@ -96,7 +96,6 @@ __device__ __forceinline__ void near_first(float& ka, int& ra, float& kb, int& r
 // object-space round trips, which happen at different moments).  The TLAS stays binary.
 template <bool COUNT, class STK, bool WIDE = false>
 __device__ __forceinline__ bool trav_step(const SceneView& sc, Ray& r, const STK& stk) {
-    if (r.sp < 0) return false;
     r.iter++;
     if (!STK::shallow && r.iter > PT_MAX_ITERS) { r.overflow = 1; return false; }   // a scene with a stack bound has proper trees: the walk ends
     if (r.sp < r.switch_pt) {                                   // :330-355 leaving the object
