@@ -24,13 +24,17 @@ struct Stack {
     int* lds;            // &s_stack[0][thread]
     int32_t* spill;      // &spill[0][slot]
     int64_t stride;      // slots per spill entry
+    // Whether any lane of the wave is past the LDS part is ONE wave-uniform branch; the per-lane choice between LDS and
+    // spill (exec-mask bookkeeping on the scalar unit, which a CU's 32 waves share) is only made behind it.
     __device__ __forceinline__ void put(int sp, int v) const {
-        if (SHALLOW || sp < LDS_N) lds[sp * BLOCK] = v; else spill[(int64_t)(sp - LDS_N) * stride] = v;
+        if (SHALLOW || !__any(sp >= LDS_N)) lds[sp * BLOCK] = v;
+        else if (sp < LDS_N) lds[sp * BLOCK] = v; else spill[(int64_t)(sp - LDS_N) * stride] = v;
     }
-    __device__ __forceinline__ int get(int sp) const {
-        if (SHALLOW) return lds[(sp < 0 ? 0 : sp) * BLOCK];          // sp = -1 ends the loop; the value read is not used
+    __device__ __forceinline__ int get(int sp) const {               // sp = -1 ends the loop; the value read then is not used
+        if (SHALLOW || !__any(sp >= LDS_N)) return lds[(sp < 0 ? 0 : sp) * BLOCK];
         return sp < 0 ? 0 : (sp < LDS_N ? lds[sp * BLOCK] : spill[(int64_t)(sp - LDS_N) * stride]);
     }
+    static constexpr int lds_n = LDS_N;
 };
 
 struct Ray {
@@ -162,7 +166,7 @@ __device__ __forceinline__ bool trav_step(const SceneView& sc, Ray& r, const STK
         const bool both = l_valid && r_valid;
         const bool take_l = l_valid && (!r_valid || l_dist < r_dist);
         if (both) {
-            if (!STK::shallow && r.sp >= PT_STACK_SIZE) { r.overflow = 1; return false; }
+            if (!STK::shallow && __any(r.sp >= STK::lds_n) && r.sp >= PT_STACK_SIZE) { r.overflow = 1; return false; }
             stk.put(r.sp, take_l ? r_child : l_child);
             r.sp += 1;
         }
