@@ -34,6 +34,7 @@ struct pt_ctx {
     // scene
     bool scene_built = false; int64_t n_tris = 0; int n_objects = 0; int n_meshes_used = 0; int32_t stack_bound = INT32_MAX;
     float4 *d_blas_nodes = nullptr, *d_blas_tris = nullptr, *d_tlas_nodes = nullptr, *d_objects = nullptr;
+    float4* d_tri_records = nullptr;                    // SceneView::tris (edges + normal per packed triangle); d_blas_tris stays the reference's buffer
     int32_t* d_tlas_perm = nullptr;
     // render
     bool render_ready = false; RenderConst rc{}; PathState ps{};
@@ -110,7 +111,7 @@ int scene_stack_bound(pt_ctx* c) {
 }
 
 SceneView scene_view(const pt_ctx* c) {
-    SceneView v; v.tlas = c->d_tlas_nodes; v.objects = c->d_objects; v.blas = c->d_blas_nodes; v.tris = c->d_blas_tris;
+    SceneView v; v.tlas = c->d_tlas_nodes; v.objects = c->d_objects; v.blas = c->d_blas_nodes; v.tris = c->d_tri_records;
     v.wide = c->traversal_mode == PT_TRAVERSAL_WIDE ? c->d_wide : nullptr;
     v.ext_mats = c->d_ext_mats; v.n_ext_mats = c->n_ext_mats; v.stack_bound = c->stack_bound;
     v.n_objects = c->n_objects; v.n_tris = (int32_t)std::min<int64_t>(c->n_tris, INT32_MAX);
@@ -156,8 +157,8 @@ int build_mesh(pt_ctx* c, Mesh& m) {
 
 void free_scene(pt_ctx* c) {
     if (c->d_wide) { dfree(c->d_wide); c->d_wide = nullptr; }
-    dfree(c->d_blas_nodes); dfree(c->d_blas_tris); dfree(c->d_tlas_nodes); dfree(c->d_objects); dfree(c->d_tlas_perm);
-    c->d_blas_nodes = c->d_blas_tris = c->d_tlas_nodes = c->d_objects = nullptr; c->d_tlas_perm = nullptr; c->scene_built = false;
+    dfree(c->d_blas_nodes); dfree(c->d_blas_tris); dfree(c->d_tlas_nodes); dfree(c->d_objects); dfree(c->d_tlas_perm); dfree(c->d_tri_records);
+    c->d_blas_nodes = c->d_blas_tris = c->d_tlas_nodes = c->d_objects = c->d_tri_records = nullptr; c->d_tlas_perm = nullptr; c->scene_built = false;
 }
 void free_render(pt_ctx* c) {
     for (auto& p : c->render_allocs) dfree(p.first);
@@ -309,6 +310,8 @@ int pt_scene_build(pt_ctx* c, const pt_instance* inst, int n_inst) {
     if ((rc = dalloc(c, &c->d_blas_tris, (size_t)off * 3, false))) return rc;
     for (Mesh& m : c->meshes)
         if (m.used) ptk_pack_mesh(m.d_nodes, m.d_tris_sorted, m.n, (int32_t)m.tri_offset, c->d_blas_nodes, c->d_blas_tris, c->stream);
+    if ((rc = dalloc(c, &c->d_tri_records, (size_t)off * 3, false))) return rc;
+    ptk_tri_records(c->d_blas_tris, off, c->d_tri_records, c->stream);
     // scene.js:42-61 scene bounds; builders.js:97-151 buildTLAS
     float sb[6] = {1e30f, 1e30f, 1e30f, -1e30f, -1e30f, -1e30f};
     std::vector<float> aabbs((size_t)n_inst * 8, 0.0f);

@@ -21,7 +21,9 @@ struct SceneView {
     const float4* tlas;      // pt_bvh_node[n_objects]
     const float4* objects;   // pt_object[n_objects]
     const float4* blas;      // pt_bvh_node[n_tris]
-    const float4* tris;      // pt_triangle[n_tris]
+    const float4* tris;      // per triangle {v0, nx}{v1 - v0, ny}{v2 - v0, nz}: the reference's pt_triangle with what every ray
+                             // would recompute from it -- the two edges (scene.js:479-481) and the unit normal
+                             // (scene.js:233) -- evaluated once at build time by the same f32 operations (k_tri_records)
     const float4* wide;      // fast mode only (pt_set_traversal_mode): compressed 4-wide collapse of the BLAS (PT_WIDE_QUADS per node), else null
     const float4* ext_mats;  // extension materials (pt_material = 2 quads each) for material ids 2.., null by default
     int32_t n_ext_mats;
@@ -91,6 +93,7 @@ void ptk_iota(int32_t* idx, int64_t n, hipStream_t s);
 void ptk_radix_tree(const uint32_t* sorted_keys, int64_t n, int32_t* parents /* 2n, zeroed */, hipStream_t s);
 void ptk_up_pass(const int32_t* idx, const float4* aabb, const int32_t* parents, int64_t n, float4* nodes /* zeroed */, hipStream_t s);
 void ptk_rearrange(const float4* tris_in, const int32_t* idx, int64_t n, float4* tris_out, hipStream_t s);
+void ptk_tri_records(const float4* tris, int64_t n, float4* records, hipStream_t s);   // SceneView::tris from pt_triangle[n]
 void ptk_pack_mesh(const float4* src_nodes, const float4* src_tris, int64_t n, int32_t offset, float4* dst_nodes, float4* dst_tris, hipStream_t s);
 // Fast mode (outside the bit-exact contract): wide[node] = the binary node `node` with each inner child
 // replaced by that child's two children -- up to four boxes per fetch -- and the boxes quantised to 8 bits per coordinate

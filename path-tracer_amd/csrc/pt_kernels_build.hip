@@ -193,6 +193,19 @@ void ptk_up_pass(const int32_t* idx, const float4* aabb, const int32_t* parents,
 void ptk_rearrange(const float4* in, const int32_t* idx, int64_t n, float4* out, hipStream_t s) {
     hipLaunchKernelGGL(k_rearrange, grid_for(n), dim3(PT_BLOCK), 0, s, in, idx, n, out);
 }
+// SceneView::tris: edges and unit normal of every packed triangle, by the expressions the extend and material kernels
+// used to evaluate per ray (same translation-unit flags: no contraction, correctly rounded divide and sqrt).
+__global__ __launch_bounds__(PT_BLOCK) void k_tri_records(const float4* __restrict__ tris, int64_t n, float4* __restrict__ rec) {
+    int64_t i = (int64_t)blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    f3 v0 = F3(tris[3 * i]), v0v1 = F3(tris[3 * i + 1]) - v0, v0v2 = F3(tris[3 * i + 2]) - v0;
+    f3 nrm = normalize3(cross3(v0v1, v0v2));
+    rec[3 * i] = make_float4(v0.x, v0.y, v0.z, nrm.x); rec[3 * i + 1] = make_float4(v0v1.x, v0v1.y, v0v1.z, nrm.y);
+    rec[3 * i + 2] = make_float4(v0v2.x, v0v2.y, v0v2.z, nrm.z);
+}
+void ptk_tri_records(const float4* tris, int64_t n, float4* records, hipStream_t s) {
+    hipLaunchKernelGGL(k_tri_records, grid_for(n), dim3(PT_BLOCK), 0, s, tris, n, records);
+}
 void ptk_pack_mesh(const float4* src_nodes, const float4* src_tris, int64_t n, int32_t offset, float4* dst_nodes, float4* dst_tris, hipStream_t s) {
     hipLaunchKernelGGL(k_pack_mesh, grid_for(n), dim3(PT_BLOCK), 0, s, src_nodes, src_tris, n, offset, dst_nodes, dst_tris);
 }

@@ -61,7 +61,7 @@ __device__ __forceinline__ float slab(f3 low, f3 high, f3 o, f3 id) {
 }
 // scene.js:478-506
 __device__ __forceinline__ float tri_hit(f3 o, f3 d, float4 a, float4 b, float4 c) {
-    f3 v0 = F3(a), v0v1 = F3(b) - v0, v0v2 = F3(c) - v0;
+    f3 v0 = F3(a), v0v1 = F3(b), v0v2 = F3(c);                  // SceneView::tris holds the edges
     f3 pvec = cross3(d, v0v2);
     float det = dot3(v0v1, pvec);
     if (__builtin_fabsf(det) < 1e-10f) return -1.0f;

@@ -72,12 +72,13 @@ __device__ __forceinline__ void shade_one(const PathState& ps, const SceneView& 
     f3 ln, lhit;
     {
         const float4* tr = sc.tris + 3 * (int64_t)hit_tri;
-        f3 v0 = F3(tr[0]), v0v1 = F3(tr[1]) - v0, v0v2 = F3(tr[2]) - v0;
+        float4 t0 = tr[0], t1 = tr[1], t2 = tr[2];
+        f3 v0 = F3(t0), v0v1 = F3(t1), v0v2 = F3(t2);             // SceneView::tris: edges and unit normal are stored
         f3 pvec = cross3(ld, v0v2);
         float det = dot3(v0v1, pvec), i_det = 1.0f / det;
         f3 tvec = lo - v0;
         f3 qvec = cross3(tvec, v0v1);
-        ln = normalize3(cross3(v0v1, v0v2));
+        ln = F3(t0.w, t1.w, t2.w);
         float ldist = dot3(v0v2, qvec) * i_det;
         lhit = lo + ld * ldist;
     }
