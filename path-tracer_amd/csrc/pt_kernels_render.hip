@@ -66,7 +66,9 @@ __global__ __launch_bounds__(PT_BLOCK) void k_count(const uint32_t* __restrict__
 // totals kept with integer atomics in logic (+25 us: 4 atomics per workgroup, profiles/r01_step_fusion_*).
 // Also measured: shading here instead of in the extend tail, with logic as its own launch (20.8 + 28.9 us per step
 // against 3 + ~12 us now, profiles/r01_cornell_1080p_64spp_kernel_stats_v3.txt); packing a workgroup's camera and
-// material slots through LDS so that whole waves run only generate or only shade (47.3 -> 47.5 us at 2 M slots: no gain).
+// material slots through LDS so that whole waves run only generate or only shade measured no gain when first tried
+// (47.3 -> 47.5 us, the kernel then waited on the state traffic); with the 88-byte state it is the default (50 -> 44.5 us
+// with the pool full, 48 -> 37 us while it drains).
 // ============================================================================================
 __device__ __forceinline__ int4 wave_sum4(int4 v) {
     for (int off = 32; off > 0; off >>= 1)
@@ -116,20 +118,36 @@ __global__ __launch_bounds__(PT_BLOCK) void k_compact_generate_shade(PathState p
             hdr->step_index += 1;
         }
     }
-    int4 off = make_int4(0, 0, 0, 0);
-    for (int w = 0; w < NW; w++) { off = add4(off, s_front[w]); if (w < wave) off = add4(off, s_wave[w]); }
-    if (code & 1u) cam_q[off.x + rank_below(b_cam)] = i;
-    if (code & 2u) mat_q[off.y + rank_below(b_mat)] = i;
+    int4 off = make_int4(0, 0, 0, 0), loc = make_int4(0, 0, 0, 0), tot = make_int4(0, 0, 0, 0);
+    for (int w = 0; w < NW; w++) { off = add4(off, s_front[w]); tot = add4(tot, s_wave[w]); if (w < wave) loc = add4(loc, s_wave[w]); }
+    off = add4(off, loc);
+    const int r_cam = rank_below(b_cam), r_mat = rank_below(b_mat);
+    if (code & 1u) cam_q[off.x + r_cam] = i;
+    if (code & 2u) mat_q[off.y + r_mat] = i;
+    int px = -1;                                                                    // -1: the slot keeps its pixel
     if (code & 4u) {
         int64_t ticket = ticket_base + off.z + rank_below(b_tix);
         if (ticket >= rc.ticket_limit) ps.state[i] |= PT_ST_RETIRED;                // logic.js:177-179
         else {                                                                      // logic.js:181-182
-            ps.pixel_index[i] = (int32_t)(ticket % ((int64_t)rc.width * rc.height));
+            px = (int32_t)(ticket % ((int64_t)rc.width * rc.height));
+            ps.pixel_index[i] = px;
             ps.state[i] &= ~(7u << 2);                                              // samples_in_pixel = 0
         }
     }
-    if (code & 1u) generate_one(ps, rc, i);
-    if (code & 2u) { int2 h = ps.hit[i]; shade_one(ps, sc, i, h.x, h.y); }
+    // The workgroup's camera slots, then its material slots, are handed to its first threads: whole waves run one body,
+    // and when the pool drains at the end of a render (a few live slots per workgroup, tools/step_profile.py) one wave
+    // does the work instead of four half-empty ones.  A new pixel index travels with its slot through LDS.
+    __shared__ int s_todo[PT_BLOCK];
+    if (code & 1u) s_todo[loc.x + r_cam] = (int)threadIdx.x;
+    if (code & 2u) s_todo[tot.x + loc.y + r_mat] = (int)threadIdx.x;
+    __shared__ int s_px[PT_BLOCK];
+    s_px[threadIdx.x] = px;
+    __syncthreads();
+    if ((int)threadIdx.x < tot.x + tot.y) {
+        const int j = s_todo[threadIdx.x], slot = b * PT_BLOCK + j;
+        if ((int)threadIdx.x < tot.x) generate_one(ps, rc, slot, s_px[j]);
+        else { int2 h = ps.hit[slot]; shade_one(ps, sc, slot, h.x, h.y); }
+    }
 }
 
 // Adds the unfinished tickets' partial sums to the image (and clears them) so that a host looking at the image in

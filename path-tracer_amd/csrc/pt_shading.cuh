@@ -21,8 +21,9 @@ __device__ __forceinline__ P3 mk3(f3 v) { return mk3(v.x, v.y, v.z); }
 // ============================================================================================
 // generate (camera.js:60-118)
 // ============================================================================================
-__device__ __forceinline__ void generate_one(const PathState& ps, const RenderConst& rc, int path) {
-    int px = ps.pixel_index[path];
+// px_new: the pixel index the slot has just been given by this launch, or -1 when it keeps its pixel
+__device__ __forceinline__ void generate_one(const PathState& ps, const RenderConst& rc, int path, int px_new) {
+    int px = px_new >= 0 ? px_new : ps.pixel_index[path];
     float seed = ps.random_seed[path];
     float2 r2 = rand2(seed);
     ps.random_seed[path] = seed + 2.0f;
