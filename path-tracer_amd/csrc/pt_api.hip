@@ -41,6 +41,7 @@ struct pt_ctx {
     float* d_image = nullptr; bool own_image = false; uint8_t* d_code = nullptr;
     int4 *d_blk_counts = nullptr; int32_t *d_cam_q = nullptr, *d_mat_q = nullptr, *d_spill = nullptr;
     StepHeader* d_hdr = nullptr; StepHeader* h_hdr = nullptr; int nblocks = 0; int64_t step = 0;
+    int64_t known_rays = -1;    // queue size in the last header the host has seen (-1: none yet); picks the compaction kernel's shape
     float4* d_ext_mats = nullptr; int n_ext_mats = 0;   // extension materials (pt_render_set_extensions)
     float4* d_wide = nullptr; int traversal_mode = 0;   // fast mode (pt_set_traversal_mode): 4-wide collapse of the packed BLAS
     std::vector<std::pair<void*, size_t>> render_allocs; std::vector<hipEvent_t> events; int64_t ticket_begin = 0;
@@ -187,7 +188,10 @@ void enqueue_step(pt_ctx* c, int count_visits, hipEvent_t ev0, hipEvent_t ev1) {
     SceneView sv = scene_view(c);
     int parity = (int)(c->step & 1);
     if (c->step == 0) ptk_first_logic(c->ps, c->rc, c->d_code, c->stream);
-    ptk_count_compact_generate_shade(c->ps, c->rc, sv, c->d_code, c->d_blk_counts, parity, c->d_hdr, c->d_cam_q, c->d_mat_q, c->stream);
+    // One compaction workgroup per count record while the step has little to do -- the first steps (camera rays only) and
+    // the ramp-down, as far as the host knows it (pt_render_run sees headers up to two batches late) -- else four.
+    int fat = c->step < 6 || (c->known_rays >= 0 && 2 * c->known_rays < c->rc.num_paths);
+    ptk_count_compact_generate_shade(c->ps, c->rc, sv, c->d_code, c->d_blk_counts, parity, c->d_hdr, c->d_cam_q, c->d_mat_q, fat, c->stream);
     if (ev0) (void)hipEventRecord(ev0, c->stream);
     ptk_extend_queue(c->ps, c->rc, sv, c->d_hdr, c->d_cam_q, c->d_mat_q, c->d_spill, count_visits, c->extend_variant, nullptr, c->d_image, c->d_code, c->stream);
     if (ev1) (void)hipEventRecord(ev1, c->stream);
@@ -214,7 +218,7 @@ int write_header(pt_ctx* c) {
     *c->h_hdr = h;
     HIPOK(c, hipMemcpyAsync(c->d_hdr, c->h_hdr, sizeof h, hipMemcpyHostToDevice, c->stream));
     HIPOK(c, hipStreamSynchronize(c->stream));
-    c->step = 0;
+    c->step = 0; c->known_rays = -1;
     return PT_OK;
 }
 
@@ -503,6 +507,7 @@ int pt_render_step(pt_ctx* c, pt_step_stats* stats) {
         int r = read_back(c, c->h_hdr, c->d_hdr, sizeof(StepHeader));
         if (r) return r;
         stats->n_camera = c->h_hdr->n_camera; stats->n_material = c->h_hdr->n_material; stats->n_rays = c->h_hdr->n_rays;
+        c->known_rays = c->h_hdr->n_rays;
         stats->step_index = c->step - 1;
     }
     return PT_OK;
@@ -551,6 +556,7 @@ int pt_render_run(pt_ctx* c, int64_t max_steps, int flags, pt_run_stats* out) {
         bool more = issued < max_steps;
         if (more) { if ((r = issue(b + 1))) return r; last = b + 1; }
         if ((r = collect(b))) return r;
+        c->known_rays = c->h_hdr[b & 1].n_rays;
         if (c->h_hdr[b & 1].first_empty_step >= 0 || !more) {
             if (last > b && (r = collect(last))) return r;    // drain the batch issued ahead
             break;

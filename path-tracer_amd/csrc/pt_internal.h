@@ -116,7 +116,7 @@ int  ptk_step_blocks(int num_paths);   // count records per step; the code array
 void ptk_first_logic(const PathState& ps, const RenderConst& rc, uint8_t* code, hipStream_t s);   // before step 0 only
 // counts -> queues, tickets, camera rays, StepHeader.  parity = step & 1 (StepHeader::ticket_next)
 void ptk_count_compact_generate_shade(const PathState& ps, const RenderConst& rc, const SceneView& sc, const uint8_t* code, int4* blk_counts, int parity, StepHeader* hdr,
-                                int32_t* cam_q, int32_t* mat_q, hipStream_t s);
+                                int32_t* cam_q, int32_t* mat_q, int fat /* one workgroup per count record: for steps with few live slots */, hipStream_t s);
 // Extend over the step's ray queue (camera ++ material), followed per slot by the next step's logic and material sample
 // (code != null; they write the decision codes the next ptk_count_compact_generate reads).  code == null: traversal only.
 // count != 0 selects the visit-counting variant.

@@ -75,23 +75,39 @@ __device__ __forceinline__ int4 wave_sum4(int4 v) {
         v = add4(v, make_int4(__shfl_xor(v.x, off), __shfl_xor(v.y, off), __shfl_xor(v.z, off), __shfl_xor(v.w, off)));
     return v;
 }
+template <int PL>
 __global__ __launch_bounds__(PT_BLOCK) void k_compact_generate_shade(PathState ps, RenderConst rc, SceneView sc, const uint8_t* __restrict__ code_in,
                                                                      const int4* __restrict__ blk_counts, int nrecords, int parity, StepHeader* hdr,
                                                                      int32_t* __restrict__ cam_q, int32_t* __restrict__ mat_q) {
-    constexpr int NW = PT_BLOCK / 64, PER = PT_STEP_BLOCK / PT_BLOCK;
-    __shared__ int4 s_wave[NW], s_front[NW], s_all[NW];
-    const int b = blockIdx.x, group = b / PER, sub = b % PER, wave = threadIdx.x >> 6, lane = lane_id();
-    int i = b * PT_BLOCK + threadIdx.x;
-    unsigned code = i < rc.num_paths ? code_in[i] : 0u;
-    unsigned long long b_cam = __ballot(code & 1u), b_mat = __ballot(code & 2u), b_tix = __ballot(code & 4u);
-    if (lane == 0) s_wave[wave] = make_int4(__popcll(b_cam), __popcll(b_mat), __popcll(b_tix), 0);
+    // A workgroup takes PL planes of 256 consecutive slots (plane-major = slot order).  PL = 1: four workgroups per count
+    // record, the shortest launch while the pool is full (6 waves per SIMD, one body per thread); PL = 4: one workgroup per
+    // record, a quarter of the workgroups and of the prefix work -- half the cost of a step that has little else to do
+    // (8 instead of 15 us for an empty pool, 24 instead of 34 us at 12 % live slots), slower with the pool full (48
+    // against 44.5 us: 5 waves per SIMD, four bodies in a row per thread).  The host picks (pt_api.hip enqueue_step).
+    constexpr int NW = PT_BLOCK / 64, PER = PT_STEP_BLOCK / (PL * PT_BLOCK);
+    static_assert(PER * PL * PT_BLOCK == PT_STEP_BLOCK, "a count record is a whole number of workgroups");
+    __shared__ int4 s_cnt[PL][NW], s_front[NW], s_all[NW];
+    __shared__ unsigned short s_todo[PL * PT_BLOCK];
+    __shared__ int s_px[PL * PT_BLOCK];
+    const int b = blockIdx.x, base = b * PL * PT_BLOCK, group = b / PER, sub = b % PER, wave = threadIdx.x >> 6, lane = lane_id();
+    unsigned code[PL]; unsigned long long b_cam[PL], b_mat[PL], b_tix[PL];
+#pragma unroll
+    for (int p = 0; p < PL; p++) {
+        int i = base + p * PT_BLOCK + (int)threadIdx.x;
+        code[p] = i < rc.num_paths ? code_in[i] : 0u;
+    }
+#pragma unroll
+    for (int p = 0; p < PL; p++) {
+        b_cam[p] = __ballot(code[p] & 1u); b_mat[p] = __ballot(code[p] & 2u); b_tix[p] = __ballot(code[p] & 4u);
+        if (lane == 0) s_cnt[p][wave] = make_int4(__popcll(b_cam[p]), __popcll(b_mat[p]), __popcll(b_tix[p]), 0);
+    }
     const int64_t ticket_base = hdr->ticket_next[parity];
     {   // counts in front of this workgroup; workgroup 0 adds up all records for the header
         const int upto = b == 0 ? nrecords : group;
         int4 acc = make_int4(0, 0, 0, 0);
         for (int j = threadIdx.x; j < upto; j += PT_BLOCK) acc = add4(acc, blk_counts[j]);
-        for (int k = 0; k < sub; k++) {
-            unsigned c = code_in[(group * PER + k) * PT_BLOCK + threadIdx.x];
+        for (int k = 0; k < sub * PL; k++) {                    // the planes of this record in front of this workgroup
+            unsigned c = code_in[group * PT_STEP_BLOCK + k * PT_BLOCK + threadIdx.x];
             acc.x += c & 1u; acc.y += (c >> 1) & 1u; acc.z += (c >> 2) & 1u;
         }
         acc = wave_sum4(acc);
@@ -118,36 +134,42 @@ __global__ __launch_bounds__(PT_BLOCK) void k_compact_generate_shade(PathState p
             hdr->step_index += 1;
         }
     }
-    int4 off = make_int4(0, 0, 0, 0), loc = make_int4(0, 0, 0, 0), tot = make_int4(0, 0, 0, 0);
-    for (int w = 0; w < NW; w++) { off = add4(off, s_front[w]); tot = add4(tot, s_wave[w]); if (w < wave) loc = add4(loc, s_wave[w]); }
-    off = add4(off, loc);
-    const int r_cam = rank_below(b_cam), r_mat = rank_below(b_mat);
-    if (code & 1u) cam_q[off.x + r_cam] = i;
-    if (code & 2u) mat_q[off.y + r_mat] = i;
-    int px = -1;                                                                    // -1: the slot keeps its pixel
-    if (code & 4u) {
-        int64_t ticket = ticket_base + off.z + rank_below(b_tix);
-        if (ticket >= rc.ticket_limit) ps.state[i] |= PT_ST_RETIRED;                // logic.js:177-179
-        else {                                                                      // logic.js:181-182
-            px = (int32_t)(ticket % ((int64_t)rc.width * rc.height));
-            ps.pixel_index[i] = px;
-            ps.state[i] &= ~(7u << 2);                                              // samples_in_pixel = 0
+    int4 off = make_int4(0, 0, 0, 0), tot = make_int4(0, 0, 0, 0), loc[PL];
+    for (int w = 0; w < NW; w++) off = add4(off, s_front[w]);
+#pragma unroll
+    for (int p = 0; p < PL; p++) {
+        loc[p] = tot;
+        for (int w = 0; w < NW; w++) { int4 c = s_cnt[p][w]; if (w < wave) loc[p] = add4(loc[p], c); tot = add4(tot, c); }
+    }
+    // Camera slots, then material slots, of the whole record are handed to the workgroup's threads in turn: whole waves
+    // run one body, and when the pool drains at the end of a render (a few live slots per record, tools/step_profile.py)
+    // one wave does the work.  A new pixel index travels with its slot through LDS.
+#pragma unroll
+    for (int p = 0; p < PL; p++) {
+        const int i = base + p * PT_BLOCK + (int)threadIdx.x, j = p * PT_BLOCK + (int)threadIdx.x;
+        const int r_cam = rank_below(b_cam[p]), r_mat = rank_below(b_mat[p]);
+        if (code[p] & 1u) { cam_q[off.x + loc[p].x + r_cam] = i; s_todo[loc[p].x + r_cam] = (unsigned short)j; }
+        if (code[p] & 2u) { mat_q[off.y + loc[p].y + r_mat] = i; s_todo[tot.x + loc[p].y + r_mat] = (unsigned short)j; }
+        int px = -1;                                                                    // -1: the slot keeps its pixel
+        if (code[p] & 4u) {
+            int64_t ticket = ticket_base + off.z + loc[p].z + rank_below(b_tix[p]);
+            if (ticket >= rc.ticket_limit) ps.state[i] |= PT_ST_RETIRED;                // logic.js:177-179
+            else {                                                                      // logic.js:181-182
+                px = (int32_t)(ticket % ((int64_t)rc.width * rc.height));
+                ps.pixel_index[i] = px;
+                ps.state[i] &= ~(7u << 2);                                              // samples_in_pixel = 0
+            }
         }
+        s_px[j] = px;
     }
-    // The workgroup's camera slots, then its material slots, are handed to its first threads: whole waves run one body,
-    // and when the pool drains at the end of a render (a few live slots per workgroup, tools/step_profile.py) one wave
-    // does the work instead of four half-empty ones.  A new pixel index travels with its slot through LDS.
-    __shared__ int s_todo[PT_BLOCK];
-    if (code & 1u) s_todo[loc.x + r_cam] = (int)threadIdx.x;
-    if (code & 2u) s_todo[tot.x + loc.y + r_mat] = (int)threadIdx.x;
-    __shared__ int s_px[PT_BLOCK];
-    s_px[threadIdx.x] = px;
     __syncthreads();
-    if ((int)threadIdx.x < tot.x + tot.y) {
-        const int j = s_todo[threadIdx.x], slot = b * PT_BLOCK + j;
-        if ((int)threadIdx.x < tot.x) generate_one(ps, rc, slot, s_px[j]);
+    auto body = [&](int t) {
+        const int j = s_todo[t], slot = base + j;
+        if (t < tot.x) generate_one(ps, rc, slot, s_px[j]);
         else { int2 h = ps.hit[slot]; shade_one(ps, sc, slot, h.x, h.y); }
-    }
+    };
+    if (PL == 1) { if ((int)threadIdx.x < tot.x + tot.y) body((int)threadIdx.x); }      // no loop: 76 registers, 6 waves per SIMD
+    else for (int t = threadIdx.x; t < tot.x + tot.y; t += PT_BLOCK) body(t);
 }
 
 // Adds the unfinished tickets' partial sums to the image (and clears them) so that a host looking at the image in
@@ -189,10 +211,11 @@ void ptk_first_logic(const PathState& ps, const RenderConst& rc, uint8_t* code, 
     hipLaunchKernelGGL(k_first_logic, grid_for(rc.num_paths), dim3(PT_BLOCK), 0, s, ps, rc, code);
 }
 void ptk_count_compact_generate_shade(const PathState& ps, const RenderConst& rc, const SceneView& sc, const uint8_t* code, int4* blk_counts, int parity, StepHeader* hdr,
-                                int32_t* cam_q, int32_t* mat_q, hipStream_t s) {
+                                int32_t* cam_q, int32_t* mat_q, int fat, hipStream_t s) {
     int nrecords = ptk_step_blocks(rc.num_paths);
     hipLaunchKernelGGL(k_count, dim3(nrecords), dim3(PT_BLOCK), 0, s, (const uint32_t*)code, blk_counts);
-    hipLaunchKernelGGL(k_compact_generate_shade, grid_for(rc.num_paths), dim3(PT_BLOCK), 0, s, ps, rc, sc, code, blk_counts, nrecords, parity, hdr, cam_q, mat_q);
+    if (fat) hipLaunchKernelGGL(k_compact_generate_shade<PT_STEP_BLOCK / PT_BLOCK>, dim3(nrecords), dim3(PT_BLOCK), 0, s, ps, rc, sc, code, blk_counts, nrecords, parity, hdr, cam_q, mat_q);
+    else hipLaunchKernelGGL(k_compact_generate_shade<1>, grid_for(rc.num_paths), dim3(PT_BLOCK), 0, s, ps, rc, sc, code, blk_counts, nrecords, parity, hdr, cam_q, mat_q);
 }
 void ptk_flush_tickets(const PathState& ps, int num_paths, float* image, hipStream_t s) {
     hipLaunchKernelGGL(k_flush_tickets, grid_for(num_paths), dim3(PT_BLOCK), 0, s, ps, num_paths, image);
