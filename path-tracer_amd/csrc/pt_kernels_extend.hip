@@ -230,7 +230,10 @@ __global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView 
     int blk = (ORDER == 2 && hdr->extend_order) ? nblk - 1 - (int)blockIdx.x : (int)blockIdx.x;
     if (blk < 0 || blk >= nblk) return;
     if (LOG && lane_id() == 0) wave_log[4 * (int64_t)(blockIdx.x * (BLOCK >> 6) + (threadIdx.x >> 6)) + 1] = 0;
-    __shared__ float4 s_scene[SCENE_QUADS > 0 ? SCENE_QUADS : 1];
+    // dynamic LDS, sized by the launcher to the scene's own quads (not to the SCENE_QUADS limit): what a workgroup does not
+    // take lets another one start in the wave slots that the finished waves of resident workgroups have already left.
+    // (Sizing the stack part to the scene's stack bound as well was measured: the run-time LDS base costs more than it returns.)
+    extern __shared__ float4 s_scene[];
     if (SCENE_QUADS > 0) {                                       // [tlas | objects | blas | tris]
         const int m4 = 4 * sc.n_objects, m12 = 12 * sc.n_objects, n4 = 4 * sc.n_tris, total = m12 + 7 * sc.n_tris;
         for (int i = threadIdx.x; i < total; i += BLOCK)
@@ -307,7 +310,8 @@ static void launch_queue(const PathState& ps, int num_paths, const SceneView& sc
                          hipStream_t s) {
     int64_t stride = pad_to(num_paths, 256);
     dim3 grid((unsigned)((num_paths + BLOCK - 1) / BLOCK));
-#define PT_LAUNCH(COUNT, LOG, LOGIC) hipLaunchKernelGGL((k_extend_queue<LDS_N, BLOCK, COUNT, ORDER, LOG, LOGIC, WIDE, SCENE_QUADS, SHALLOW>), grid, dim3(BLOCK), 0, s, ps, sc, hdr, \
+    const size_t scene_lds = SCENE_QUADS > 0 ? 16 * (size_t)(12 * sc.n_objects + 7 * sc.n_tris) : 0;
+#define PT_LAUNCH(COUNT, LOG, LOGIC) hipLaunchKernelGGL((k_extend_queue<LDS_N, BLOCK, COUNT, ORDER, LOG, LOGIC, WIDE, SCENE_QUADS, SHALLOW>), grid, dim3(BLOCK), scene_lds, s, ps, sc, hdr, \
                                                        cam_q, mat_q, spill, stride, wave_log, image, code, max_nb)
     if (wave_log)    PT_LAUNCH(false, true, false);    // measurement replays (code == null): traversal only, idempotent
     else if (!code)  PT_LAUNCH(false, false, false);
