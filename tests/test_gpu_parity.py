@@ -438,6 +438,11 @@ def test_error_behaviour(pta, device):
     with pytest.raises(pta.capi.PtError, match="not been built"):
         pta.init_path_tracer({"device": dev2, "scene": None, "image": {"width": 8, "height": 8},
                               "camera": {"position": [0, 0, 0], "lookAt": [1, 0, 0], "fov": 60}, "settings": {"samples": 8}})
+    desc = pta.scenes.floor_scene()
+    ok = pta.scenes.populate(pta.init_scene(dev2), desc); ok.build()
+    with pytest.raises(pta.capi.PtError, match="max_nb"):         # num_bounces shares a word with two other members: bounded
+        pta.init_path_tracer({"device": dev2, "scene": ok, "image": {"width": 8, "height": 8}, "camera": desc["camera"],
+                              "settings": {"samples": 8, "numPaths": 64, "maxNb": (1 << 22) + 1}})
     sc = pta.init_scene(dev2)
     with pytest.warns(UserWarning):
         sc.instance_mesh(3, [0, 0, 0], [0, 0, 0], [1, 1, 1], 0)
