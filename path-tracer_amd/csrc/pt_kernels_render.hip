@@ -1,8 +1,8 @@
 // pt_kernels_render.hip -- the wavefront integrator on gfx950 (extend is in pt_kernels_extend.hip).
 //
 // One step() = count -> compact+generate+shade -> extend(+logic): three launches on one stream, no host round trip in
-// between (the reference awaits the queue after each of its four dispatches, path-tracer.js:86-107).  The thread
-// that compacts a slot also produces the slot's next ray: the camera ray as soon as the pixel ticket is known, or
+// between (the reference awaits the queue after each of its four dispatches, path-tracer.js:86-107).  The launch
+// that compacts the slots also produces their next rays: the camera ray as soon as the pixel ticket is known, or
 // the bounce ray (the camera and material kernels only touch their slot's own state); the thread that traced a slot's
 // ray runs the slot's logic for the next step (pt_kernels_extend.hip).
 // Queue appends are order-preserving: wave64 ballots give each lane its rank, the count records in front of a
@@ -56,12 +56,12 @@ __global__ __launch_bounds__(PT_BLOCK) void k_count(const uint32_t* __restrict__
 
 // ============================================================================================
 // compact + generate + shade: stable scatter into the camera / material queues and pixel tickets (logic.js:155-219),
-// then the slot's next ray by the same thread -- the camera ray of a slot that starts a sample (camera.js:60-118) or
+// then the slots' next rays by the same workgroup -- the camera ray of a slot that starts a sample (camera.js:60-118) or
 // the bounce ray of a slot that continues (material.js:75-120); both only touch that slot's own state, so neither
 // waits for a queue.  Workgroup 0 also closes the step's books in the StepHeader.
-// No scan launch: k_count leaves one record per 1024 slots (~1000 per step); a workgroup here (256 slots) adds up
-// the records in front of its 1024-slot group (<= 4 16-B loads per thread, L2 resident) and re-counts the codes of the
-// <= 3 workgroups in front of it inside the group.  Measured alternatives: a one-workgroup scan launch (9 us of
+// No scan launch: k_count leaves one record per 1024 slots (~1000 per step); a workgroup here adds up the records in
+// front of its 1024-slot group (<= 4 16-B loads per thread, L2 resident) and, when it is one of four per group,
+// re-counts the codes of the <= 3 workgroups in front of it inside the group.  Measured alternatives: a one-workgroup scan launch (9 us of
 // pure latency per step), "last logic workgroup to arrive scans" (+100 us of contended arrivals), per-64-workgroup
 // totals kept with integer atomics in logic (+25 us: 4 atomics per workgroup, profiles/r01_step_fusion_*).
 // Also measured: shading here instead of in the extend tail, with logic as its own launch (20.8 + 28.9 us per step
