@@ -4,10 +4,10 @@
     python bench.py --gpus N --steps K --warmup W
 
 Metric (BASELINE.json): Mrays/s at 1920x1080.  Workload at N=1: configs[1], the Cornell box at 1920x1080,
-64 spp, 2,000,000 path slots in flight (--paths; the reference hard-codes NUM_PATHS = 1,000,000).  One "step" = one
-complete render of that frame: every wavefront iteration (count -> compact+generate+shade -> extend+logic) until both
+64 spp, 3 path pools of 750,000 slots in flight (--pools, --paths; the reference has one pool of NUM_PATHS = 1,000,000).
+One "step" = one complete render of that frame: every wavefront iteration (count -> compact+generate+shade -> extend+logic) until both
 stage-2 queues are empty, with the scene and all buffers already resident in HBM.  N > 1: one process per GPU (torchrun),
-each GPU renders the full 64 spp with its own RNG streams (slot_base = rank * NUM_PATHS) and its own ticket
+each GPU renders the full 64 spp with its own RNG streams (slot_base = (rank * pools + pool) * NUM_PATHS) and its own ticket
 range, i.e. the node accumulates N*64 spp ("weak": per-GPU work fixed); the per-GPU accumulation buffers are
 combined by one RCCL sum-reduce to rank 0 inside the timed region of every step.
 
@@ -48,8 +48,11 @@ def main():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--spp", type=int, default=0)
-    ap.add_argument("--paths", type=int, default=2_000_000,
-                    help="path slots in flight per GPU (the reference hard-codes 1,000,000, path-tracer.js:4; 2,000,000 is the measured optimum on MI355X, profiles/r01_pool_size_sweep.json)")
+    ap.add_argument("--paths", type=int, default=750_000,
+                    help="path slots per pool (the reference has one pool of 1,000,000, path-tracer.js:4); 3 pools of 750,000 is the measured optimum "
+                         "on MI355X, one pool of 2,000,000 the best single pool (profiles/r01_pool_size_sweep_v3.json)")
+    ap.add_argument("--pools", type=int, default=3,
+                    help="independent path pools per GPU, --paths slots each, driven together on their own streams (pt_render_run_many)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=64, help="spp of the bounded CPU-baseline sample")
     ap.add_argument("--png", default="", help="write the tonemapped frame of the last step here (rank 0)")
@@ -94,7 +97,7 @@ def main():
 
     # per-GPU share: full spp each, distinct ticket range and RNG streams
     image = torch.zeros(h * w * 4, dtype=torch.float32, device="cuda")
-    settings = pta.multigpu.weak_share(rank, world, w, h, spp, args.paths)
+    settings = pta.multigpu.weak_share(rank, world, w, h, spp, args.paths, pools=args.pools)
     settings["imageDev"] = image.data_ptr()
     pt = pta.init_path_tracer({"device": dev, "scene": scene, "image": {"width": w, "height": h}, "camera": desc["camera"], "settings": settings})
 
@@ -122,6 +125,7 @@ def main():
         rs = one_step(not args.no_extend_timing, False)
         rays += rs.total_rays; samples += rs.total_samples; extend_ms += rs.extend_ms; launches += rs.extend_launches
         steps_per_render = rs.steps
+        launches_per_render = sum(r.steps for r in pt.last_pool_stats) if args.pools > 1 else rs.steps   # extend launches of all pools
         if rs.stack_overflows:
             raise SystemExit(f"traversal guard hit on {rs.stack_overflows} rays")
     barrier()
@@ -141,17 +145,17 @@ def main():
             disp = pta.init_display({"device": dev, "canvas": args.png, "image": {"buffer": image.data_ptr(), "width": w, "height": h}})
             disp.draw()
         # one extend launch in eight is bracketed by HIP events (pt_render_run); mean over those, scaled to all launches
-        all_launches = int(steps_per_render) * args.steps
+        all_launches = int(launches_per_render) * args.steps
         avg_s = extend_ms / 1e3 / max(launches, 1)
         ext_s = avg_s * all_launches
-        bytes_per_launch = trav_bytes / max(int(steps_per_render), 1)
+        bytes_per_launch = trav_bytes / max(int(launches_per_render), 1)
         achieved = bytes_per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
         out = {
             "metric": "Mrays/s", "value": round(all_rays / elapsed / 1e6, 3), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {info.n_tris} tris / {info.n_objects} instances, {w}x{h}, {spp} spp per GPU, "
-                                   f"{args.paths} path slots (reference: 1000000), reference bounce rules" + (", FAST MODE: 4-wide BVH traversal, not bit-exact" if args.fast else ""), "spp_total": spp * world,
+                                   f"{args.pools} pool(s) of {args.paths} path slots (reference: 1 pool of 1000000), reference bounce rules" + (", FAST MODE: 4-wide BVH traversal, not bit-exact" if args.fast else ""), "spp_total": spp * world,
                        "parallelism": f"spp-split x{world}, RCCL sum-reduce of the accumulation buffer"},
             "samples_per_s": round(all_samples / elapsed, 1),
             "rays_per_render_per_gpu": rays // args.steps, "wavefront_iterations_per_render": int(steps_per_render),
@@ -163,7 +167,9 @@ def main():
                          "extend_share_of_step": round(ext_s / elapsed, 4),
                          "note": "achieved = algorithmic traversal bytes / measured launch time; the kernel also runs the next step's "
                                  "logic, whose bytes are not counted.  A value above the HBM peak means the scene's nodes are served "
-                                 "from L2/LDS-side caches: `traffic` is what actually crossed the HBM interface"},
+                                 "from L2/LDS-side caches: `traffic` is what actually crossed the HBM interface.  With several pools the "
+                                 "launches of different pools overlap on the GPU, so a launch's measured time includes the time it shared "
+                                 "the CUs with others (extend_share_of_step can exceed 1); --pools 1 gives the kernel alone"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pta, desc, w, h, args.cpu_spp, args.paths)

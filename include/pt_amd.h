@@ -150,6 +150,18 @@ enum { PT_RUN_TIME_EXTEND = 1, PT_RUN_COUNT_BYTES = 2 };
  * stage-2 queues are empty (or max_steps).  flags: PT_RUN_* . */
 int pt_render_run(pt_ctx* ctx, int64_t max_steps, int flags, pt_run_stats* out);
 
+/* ---- several path pools on one GPU (NO reference counterpart: SURVEY 8e's sample split, applied inside one device) ----
+ * pt_create_sharing_scene: a second context on src's device that borrows src's built scene (no copy); it has its own
+ * stream and its own render state (pt_render_init with its own slot_base / ticket range, like one GPU of a multi-GPU
+ * render; give every context the same image_dev to accumulate one image).  It cannot upload meshes, build a scene or
+ * change the traversal mode; destroy it before src, and rebuild nothing in src while it lives.
+ * pt_render_run_many: pt_render_run over n such contexts at once from one host thread -- their batches of steps are
+ * issued in turn on their own streams, so that one pool's compaction launches run in the tail of another's extend
+ * launch.  out: n entries (or NULL).  Every pool is bit-identical to the oracle run with the same share; overlapping
+ * pools only change when launches run. */
+int pt_create_sharing_scene(pt_ctx* src, pt_ctx** out);
+int pt_render_run_many(pt_ctx** ctxs, int n, int64_t max_steps, int flags, pt_run_stats* out);
+
 /* replaces: pt.getImageBuffer() (path-tracer.js:125-127) + a read-back the reference lacks.
  * rgba: W*H*4 floats (rgb = sum of radiance, a = finished samples; logic.js:146-149). */
 int pt_image_read(pt_ctx* ctx, float* rgba, int64_t n_floats);

@@ -74,6 +74,8 @@ SIGNATURES = {
     "pt_render_set_extensions": (C.c_int, [C.c_void_p, C.POINTER(PtRenderExt)]),
     "pt_render_step": (C.c_int, [C.c_void_p, C.POINTER(PtStepStats)]),
     "pt_render_run": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.POINTER(PtRunStats)]),
+    "pt_create_sharing_scene": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "pt_render_run_many": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int, C.POINTER(PtRunStats)]),
     "pt_image_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "pt_image_dev_ptr": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "pt_path_state_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),

@@ -32,6 +32,7 @@ struct pt_ctx {
     int device = 0; int extend_variant = 0; hipStream_t stream = nullptr; bool own_stream = false; std::string err;
     std::vector<Mesh> meshes;
     // scene
+    bool scene_borrowed = false;   // pt_create_sharing_scene: the scene buffers below belong to another context
     bool scene_built = false; int64_t n_tris = 0; int n_objects = 0; int n_meshes_used = 0; int32_t stack_bound = INT32_MAX;
     float4 *d_blas_nodes = nullptr, *d_blas_tris = nullptr, *d_tlas_nodes = nullptr, *d_objects = nullptr;
     float4* d_tri_records = nullptr;                    // SceneView::tris (edges + normal per packed triangle); d_blas_tris stays the reference's buffer
@@ -157,6 +158,11 @@ int build_mesh(pt_ctx* c, Mesh& m) {
 }
 
 void free_scene(pt_ctx* c) {
+    if (c->scene_borrowed) {
+        c->d_wide = nullptr;
+        c->d_blas_nodes = c->d_blas_tris = c->d_tlas_nodes = c->d_objects = c->d_tri_records = nullptr; c->d_tlas_perm = nullptr; c->scene_built = false;
+        return;
+    }
     if (c->d_wide) { dfree(c->d_wide); c->d_wide = nullptr; }
     dfree(c->d_blas_nodes); dfree(c->d_blas_tris); dfree(c->d_tlas_nodes); dfree(c->d_objects); dfree(c->d_tlas_perm); dfree(c->d_tri_records);
     c->d_blas_nodes = c->d_blas_tris = c->d_tlas_nodes = c->d_objects = c->d_tri_records = nullptr; c->d_tlas_perm = nullptr; c->scene_built = false;
@@ -244,6 +250,19 @@ int pt_create(int device_id, pt_ctx** out) {
     return PT_OK;
 }
 
+int pt_create_sharing_scene(pt_ctx* src, pt_ctx** out) {
+    if (!src || !out) return fail(src, PT_ERR_ARG, "pt_create_sharing_scene: null argument");
+    if (!src->scene_built) return fail(src, PT_ERR_STATE, "scene has not been built yet");
+    int r = pt_create(src->device, out);
+    if (r) return r;
+    pt_ctx* c = *out;
+    c->scene_borrowed = true; c->scene_built = true; c->extend_variant = src->extend_variant;
+    c->n_tris = src->n_tris; c->n_objects = src->n_objects; c->n_meshes_used = src->n_meshes_used; c->stack_bound = src->stack_bound;
+    c->d_blas_nodes = src->d_blas_nodes; c->d_blas_tris = src->d_blas_tris; c->d_tlas_nodes = src->d_tlas_nodes; c->d_objects = src->d_objects;
+    c->d_tlas_perm = src->d_tlas_perm; c->d_tri_records = src->d_tri_records; c->d_wide = src->d_wide; c->traversal_mode = src->traversal_mode;
+    return PT_OK;
+}
+
 void pt_destroy(pt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
@@ -276,6 +295,7 @@ int pt_sync(pt_ctx* c) {
 // ------------------------------------------------------------------------------------------ scene
 int pt_mesh_upload(pt_ctx* c, const float* tris12, int64_t n_tris, const float bounds[6]) {
     if (!c || !tris12 || !bounds) return fail(c, PT_ERR_ARG, "pt_mesh_upload: null argument");
+    if (c->scene_borrowed) return fail(c, PT_ERR_STATE, "pt_mesh_upload: this context borrows another context's scene");
     if (n_tris < 1 || n_tris > (1ll << 30)) return fail(c, PT_ERR_ARG, "pt_mesh_upload: n_tris must be in [1, 2^30]");
     HIPOK(c, hipSetDevice(c->device));
     Mesh m; m.n = n_tris; memcpy(m.bounds, bounds, 24);
@@ -289,6 +309,7 @@ int pt_mesh_upload(pt_ctx* c, const float* tris12, int64_t n_tris, const float b
 
 int pt_scene_build(pt_ctx* c, const pt_instance* inst, int n_inst) {
     if (!c || !inst) return fail(c, PT_ERR_ARG, "pt_scene_build: null argument");
+    if (c->scene_borrowed) return fail(c, PT_ERR_STATE, "pt_scene_build: this context borrows another context's scene");
     if (n_inst < 1) return fail(c, PT_ERR_ARG, "pt_scene_build: the scene needs at least one instance");
     HIPOK(c, hipSetDevice(c->device));
     for (int i = 0; i < n_inst; i++)
@@ -347,6 +368,7 @@ int pt_scene_build(pt_ctx* c, const pt_instance* inst, int n_inst) {
 
 int pt_set_traversal_mode(pt_ctx* c, int mode) {
     if (!c || (mode != PT_TRAVERSAL_REFERENCE && mode != PT_TRAVERSAL_WIDE)) return fail(c, PT_ERR_ARG, "pt_set_traversal_mode: unknown mode");
+    if (c->scene_borrowed) return fail(c, PT_ERR_STATE, "pt_set_traversal_mode: this context borrows another context's scene (set the mode there first)");
     HIPOK(c, hipSetDevice(c->device));
     HIPOK(c, hipStreamSynchronize(c->stream));
     c->traversal_mode = mode;
@@ -513,70 +535,102 @@ int pt_render_step(pt_ctx* c, pt_step_stats* stats) {
     return PT_OK;
 }
 
-int pt_render_run(pt_ctx* c, int64_t max_steps, int flags, pt_run_stats* out) {
-    if (!c) return PT_ERR_ARG;
-    if (!c->render_ready) return fail(c, PT_ERR_STATE, "pt_render_run: pt_render_init has not been called");
-    HIPOK(c, hipSetDevice(c->device));
-    const int POLL = 8;   // steps between looks at the queue sizes (the reference never looks: main.js:61-72)
+// pt_render_run over n contexts at once, from one host thread.  Batches of POLL steps are issued one ahead of the host's
+// look at the queue sizes: batch b+1 is on a context's stream before the host waits for the header copy that followed its
+// batch b, so the GPU never idles for the read-back (a render ends with up to 2*POLL - 1 empty steps instead).  With
+// several contexts (pt_create_sharing_scene) the batches are issued in turn on the contexts' own streams, and one context's
+// count / compaction launches run in the tail of another's extend launch.
+// PT_RUN_TIME_EXTEND: one extend launch per batch is bracketed by events, at a position that rotates through the batch.
+// (Events around every launch were measured to cost 5.5 % of the render: each record is a barrier packet between two
+// kernels of a 120 us step.)
+namespace {
+struct RunState { pt_ctx* c; double extend_ms = 0.0; int64_t launches = 0, issued = 0, last = 0; bool had_timed[2] = {false, false}, more = false, done = false; };
+const int POLL = 8;   // steps between looks at the queue sizes (the reference never looks: main.js:61-72)
+int run_issue(RunState& rs, int64_t batch, int64_t max_steps, bool timed, int count) {
+    pt_ctx* c = rs.c;
+    int p = (int)(batch & 1); rs.had_timed[p] = false;
+    for (int k = 0; k < POLL && rs.issued < max_steps; k++, rs.issued++) {
+        bool t = timed && k == (int)(batch % POLL);
+        if (t) rs.had_timed[p] = true;
+        enqueue_step(c, count, t ? c->events[3 * p] : nullptr, t ? c->events[3 * p + 1] : nullptr);
+    }
+    HIPOK(c, hipGetLastError());
+    HIPOK(c, hipMemcpyAsync(c->h_hdr + p, c->d_hdr, sizeof(StepHeader), hipMemcpyDeviceToHost, c->stream));
+    HIPOK(c, hipEventRecord(c->events[3 * p + 2], c->stream));
+    return PT_OK;
+}
+int run_collect(RunState& rs, int64_t batch) {
+    pt_ctx* c = rs.c;
+    int p = (int)(batch & 1);
+    HIPOK(c, hipEventSynchronize(c->events[3 * p + 2]));
+    if (rs.had_timed[p]) { float ms = 0; HIPOK(c, hipEventElapsedTime(&ms, c->events[3 * p], c->events[3 * p + 1])); rs.extend_ms += ms; rs.launches++; }
+    return PT_OK;
+}
+}  // namespace
+
+int pt_render_run_many(pt_ctx** ctxs, int n, int64_t max_steps, int flags, pt_run_stats* out) {
+    if (!ctxs || n < 1) return PT_ERR_ARG;
+    for (int i = 0; i < n; i++) {
+        if (!ctxs[i]) return PT_ERR_ARG;
+        if (!ctxs[i]->render_ready) return fail(ctxs[i], PT_ERR_STATE, "pt_render_run: pt_render_init has not been called");
+        if (ctxs[i]->device != ctxs[0]->device) return fail(ctxs[i], PT_ERR_ARG, "pt_render_run_many: the contexts are on different devices");
+        for (int k = 0; k < i; k++) if (ctxs[k] == ctxs[i]) return fail(ctxs[i], PT_ERR_ARG, "pt_render_run_many: the same context twice");
+    }
+    HIPOK(ctxs[0], hipSetDevice(ctxs[0]->device));
     bool timed = (flags & PT_RUN_TIME_EXTEND) != 0; int count = (flags & PT_RUN_COUNT_BYTES) ? 1 : 0;
-    if (c->events.empty()) {   // per batch parity: [0,1] bracket a timed extend launch, [2] marks "header copy landed"
-        c->events.resize(6);
-        for (hipEvent_t& e : c->events) HIPOK(c, hipEventCreate(&e));
-    }
-    // Batches of POLL steps are issued one ahead of the host's look at the queue sizes: batch b+1 is on the stream before
-    // the host waits for the header copy that followed batch b, so the GPU never idles for the read-back (a render ends
-    // with up to 2*POLL - 1 empty steps of ~15 us instead).
-    // PT_RUN_TIME_EXTEND: one extend launch per batch is bracketed by events, at a position that rotates through the
-    // batch.  (Events around every launch were measured to cost 5.5 % of the render: each record is a barrier packet
-    // between two kernels of a 120 us step.)
-    double extend_ms = 0.0; int64_t launches = 0, issued = 0;
     if (max_steps <= 0) max_steps = INT64_MAX;
-    bool had_timed[2] = {false, false};
-    auto issue = [&](int64_t batch) -> int {
-        int p = (int)(batch & 1); had_timed[p] = false;
-        for (int k = 0; k < POLL && issued < max_steps; k++, issued++) {
-            bool t = timed && k == (int)(batch % POLL);
-            if (t) had_timed[p] = true;
-            enqueue_step(c, count, t ? c->events[3 * p] : nullptr, t ? c->events[3 * p + 1] : nullptr);
+    std::vector<RunState> rs((size_t)n);
+    int r;
+    for (int i = 0; i < n; i++) {
+        pt_ctx* c = rs[i].c = ctxs[i];
+        if (c->events.empty()) {   // per batch parity: [0,1] bracket a timed extend launch, [2] marks "header copy landed"
+            c->events.resize(6);
+            for (hipEvent_t& e : c->events) HIPOK(c, hipEventCreate(&e));
         }
-        HIPOK(c, hipGetLastError());
-        HIPOK(c, hipMemcpyAsync(c->h_hdr + p, c->d_hdr, sizeof(StepHeader), hipMemcpyDeviceToHost, c->stream));
-        HIPOK(c, hipEventRecord(c->events[3 * p + 2], c->stream));
-        return PT_OK;
-    };
-    auto collect = [&](int64_t batch) -> int {
-        int p = (int)(batch & 1);
-        HIPOK(c, hipEventSynchronize(c->events[3 * p + 2]));
-        if (had_timed[p]) { float ms = 0; HIPOK(c, hipEventElapsedTime(&ms, c->events[3 * p], c->events[3 * p + 1])); extend_ms += ms; launches++; }
-        return PT_OK;
-    };
-    int r = issue(0); if (r) return r;
-    int64_t last = 0;   // last batch issued
+        if ((r = run_issue(rs[i], 0, max_steps, timed, count))) return r;
+    }
     for (int64_t b = 0;; b++) {
-        bool more = issued < max_steps;
-        if (more) { if ((r = issue(b + 1))) return r; last = b + 1; }
-        if ((r = collect(b))) return r;
-        c->known_rays = c->h_hdr[b & 1].n_rays;
-        if (c->h_hdr[b & 1].first_empty_step >= 0 || !more) {
-            if (last > b && (r = collect(last))) return r;    // drain the batch issued ahead
-            break;
+        for (RunState& s : rs) {
+            if (s.done) continue;
+            s.more = s.issued < max_steps;
+            if (s.more) { if ((r = run_issue(s, b + 1, max_steps, timed, count))) return r; s.last = b + 1; }
         }
+        bool all_done = true;
+        for (RunState& s : rs) {
+            if (s.done) continue;
+            pt_ctx* c = s.c;
+            if ((r = run_collect(s, b))) return r;
+            c->known_rays = c->h_hdr[b & 1].n_rays;
+            if (c->h_hdr[b & 1].first_empty_step >= 0 || !s.more) {
+                if (s.last > b && (r = run_collect(s, s.last))) return r;    // drain the batch issued ahead
+                s.done = true;
+            } else all_done = false;
+        }
+        if (all_done) break;
     }
-    if (last & 1) c->h_hdr[0] = c->h_hdr[1];                   // the final header lives in h_hdr[0] for the code below
-    if (c->h_hdr->first_empty_step < 0) {   // stopped by max_steps: bring the image up to date for the caller
-        ptk_flush_tickets(c->ps, c->rc.num_paths, c->d_image, c->stream);
-        HIPOK(c, hipStreamSynchronize(c->stream));
-    }
-    if (out) {
-        const StepHeader& h = *c->h_hdr;
-        out->steps = h.first_empty_step >= 0 ? h.first_empty_step + 1 : h.step_index;
-        out->total_rays = h.total_rays; out->total_samples = h.total_samples; out->stack_overflows = (int64_t)h.overflow;
-        out->extend_ms = extend_ms; out->extend_launches = launches;
-        unsigned long long v[4] = {0, 0, 0, 0};
-        for (int sl = 0; sl < 64; sl++) for (int k = 0; k < 4; k++) v[k] += h.visits[sl][k];
-        out->traversal_bytes = count ? (int64_t)(44 * h.total_rays + 64 * v[0] + 48 * v[1] + 128 * (v[2] + v[3])) : 0;
+    for (int i = 0; i < n; i++) {
+        pt_ctx* c = ctxs[i];
+        if (rs[i].last & 1) c->h_hdr[0] = c->h_hdr[1];             // the final header lives in h_hdr[0] for the code below
+        if (c->h_hdr->first_empty_step < 0) {   // stopped by max_steps: bring the image up to date for the caller
+            ptk_flush_tickets(c->ps, c->rc.num_paths, c->d_image, c->stream);
+            HIPOK(c, hipStreamSynchronize(c->stream));
+        }
+        if (out) {
+            const StepHeader& h = *c->h_hdr; pt_run_stats* o = out + i;
+            o->steps = h.first_empty_step >= 0 ? h.first_empty_step + 1 : h.step_index;
+            o->total_rays = h.total_rays; o->total_samples = h.total_samples; o->stack_overflows = (int64_t)h.overflow;
+            o->extend_ms = rs[i].extend_ms; o->extend_launches = rs[i].launches;
+            unsigned long long v[4] = {0, 0, 0, 0};
+            for (int sl = 0; sl < 64; sl++) for (int k = 0; k < 4; k++) v[k] += h.visits[sl][k];
+            o->traversal_bytes = count ? (int64_t)(44 * h.total_rays + 64 * v[0] + 48 * v[1] + 128 * (v[2] + v[3])) : 0;
+        }
     }
     return PT_OK;
+}
+
+int pt_render_run(pt_ctx* c, int64_t max_steps, int flags, pt_run_stats* out) {
+    if (!c) return PT_ERR_ARG;
+    return pt_render_run_many(&c, 1, max_steps, flags, out);
 }
 
 int pt_image_read(pt_ctx* c, float* rgba, int64_t n_floats) {

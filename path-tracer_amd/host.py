@@ -158,12 +158,18 @@ def compute_instances(objects, mesh_bounds, mesh_handles):
 class Device:
     """Stands in for the reference's GPUDevice (main.js:3-4): one pt_ctx on one MI355X."""
 
-    def __init__(self, device_id=0, stream=None):
+    def __init__(self, device_id=0, stream=None, sharing=None):
         self.lib = capi.load()
         h = C.c_void_p()
-        rc = self.lib.pt_create(int(device_id), C.byref(h))
-        if rc < 0:
-            raise capi.PtError(f"pt_create failed ({rc}): {self.lib.pt_last_error(None).decode()}")
+        if sharing is not None:      # a second context on the same GPU that borrows `sharing`'s built scene (pt_amd.h)
+            rc = self.lib.pt_create_sharing_scene(sharing.ctx, C.byref(h))
+            if rc < 0:
+                raise capi.PtError(f"pt_create_sharing_scene failed ({rc}): {self.lib.pt_last_error(sharing.ctx).decode()}")
+            self.parent = sharing    # keeps the scene's owner alive
+        else:
+            rc = self.lib.pt_create(int(device_id), C.byref(h))
+            if rc < 0:
+                raise capi.PtError(f"pt_create failed ({rc}): {self.lib.pt_last_error(None).decode()}")
         self.ctx = h
         if stream is not None:
             self.call("pt_set_stream", C.c_void_p(stream))
@@ -371,7 +377,72 @@ class PathTracer:
         return out[: n.value]
 
 
+class PooledPathTracer:
+    """settings.pools = K > 1 (no reference counterpart): K independent path pools of settings.numPaths slots each on one
+    GPU -- SURVEY 8e's sample split applied inside the device.  Pool k is a context that borrows the scene
+    (pt_create_sharing_scene), has its own stream, RNG streams (slotBase + k * numPaths) and an equal part of this GPU's
+    pixel tickets, and adds into the one image; run() drives them together (pt_render_run_many), so that one pool's
+    compaction launches run in the tail of another's extend launch.  Every pool is bit-identical to the oracle's run of
+    the same share (`pools[k]` is an ordinary PathTracer: step(), field(), queue())."""
+
+    def __init__(self, params):
+        s = dict(params["settings"])
+        k_pools = int(s.pop("pools"))
+        w, h = int(params["image"]["width"]), int(params["image"]["height"])
+        num_paths = int(s.get("numPaths", 0)) or 1_000_000
+        total = (w * h * int(s["samples"]) + 7) // 8                           # logic.js:177
+        t0 = int(s.get("ticketBegin", 0)); t1 = int(s.get("ticketEnd", -1))
+        if t1 < 0:
+            t0, t1 = 0, total
+        base = int(s.get("slotBase", 0))
+        self.device, self.width, self.height = params["device"], w, h
+        self.pools = []
+        image = s.get("imageDev", None)
+        for k in range(k_pools):
+            dev = params["device"] if k == 0 else Device(sharing=params["device"])
+            sk = dict(s, numPaths=num_paths, slotBase=base + k * num_paths, imageDev=image,
+                      ticketBegin=t0 + (t1 - t0) * k // k_pools, ticketEnd=t0 + (t1 - t0) * (k + 1) // k_pools)
+            pt = PathTracer(dict(params, device=dev, settings=sk))
+            if image is None:
+                image = pt.get_image_buffer()                                   # pool 0 owns the image, the others add into it
+            self.pools.append(pt)
+
+    def reset(self):
+        for pt in self.pools:
+            pt.reset()
+
+    def run(self, max_steps=0, time_extend=False, count_bytes=False):
+        n = len(self.pools)
+        ctxs = (C.c_void_p * n)(*[pt.device.ctx for pt in self.pools])
+        rs = (capi.PtRunStats * n)()
+        flags = (capi.PT_RUN_TIME_EXTEND if time_extend else 0) | (capi.PT_RUN_COUNT_BYTES if count_bytes else 0)
+        lib = self.device.lib
+        capi.check(lib, self.device.ctx, lib.pt_render_run_many(ctxs, n, int(max_steps), flags, rs), "pt_render_run_many")
+        out = capi.PtRunStats()
+        out.steps = max(r.steps for r in rs)
+        for f in ("total_rays", "total_samples", "stack_overflows", "extend_launches", "traversal_bytes"):
+            setattr(out, f, sum(getattr(r, f) for r in rs))
+        out.extend_ms = sum(r.extend_ms for r in rs)
+        self.last_pool_stats = list(rs)
+        return out
+
+    def get_image_buffer(self):
+        return self.pools[0].get_image_buffer()
+
+    def read_image(self):
+        img = None
+        for pt in reversed(self.pools):          # each read first adds that pool's unfinished tickets; pool 0's read sees them all
+            img = pt.read_image()
+        return img
+
+    def destroy(self):
+        for pt in self.pools[1:]:
+            pt.device.destroy()
+
+
 def init_path_tracer(params):
+    if int(params["settings"].get("pools", 1)) > 1:
+        return PooledPathTracer(params)
     return PathTracer(params)
 
 

@@ -12,17 +12,18 @@ def tickets_for(width, height, spp):
     return (width * height * spp + SAMPLES_PER_TICKET - 1) // SAMPLES_PER_TICKET     # logic.js:177
 
 
-def weak_share(rank, world, width, height, spp_per_gpu, num_paths):
-    """Every GPU renders spp_per_gpu; the node accumulates world * spp_per_gpu samples per pixel."""
+def weak_share(rank, world, width, height, spp_per_gpu, num_paths, pools=1):
+    """Every GPU renders spp_per_gpu; the node accumulates world * spp_per_gpu samples per pixel.
+    pools: path pools per GPU (host.PooledPathTracer), num_paths slots each."""
     t = tickets_for(width, height, spp_per_gpu)
-    return {"samples": spp_per_gpu * world, "numPaths": num_paths, "slotBase": rank * num_paths,
+    return {"samples": spp_per_gpu * world, "numPaths": num_paths, "slotBase": rank * num_paths * pools, "pools": pools,
             "ticketBegin": rank * t, "ticketEnd": (rank + 1) * t}
 
 
-def strong_share(rank, world, width, height, spp_total, num_paths):
+def strong_share(rank, world, width, height, spp_total, num_paths, pools=1):
     """A fixed spp_total is split evenly: GPU g takes tickets [g*T/G, (g+1)*T/G)."""
     t = tickets_for(width, height, spp_total)
-    return {"samples": spp_total, "numPaths": num_paths, "slotBase": rank * num_paths,
+    return {"samples": spp_total, "numPaths": num_paths, "slotBase": rank * num_paths * pools, "pools": pools,
             "ticketBegin": rank * t // world, "ticketEnd": (rank + 1) * t // world}
 
 

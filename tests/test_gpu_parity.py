@@ -562,3 +562,36 @@ def test_staged_scene_stack_bound(pta, orc, device, built):
             assert_state_equal(pt, orr, step)
     finally:
         dev2.destroy()
+
+
+def test_pools_on_one_gpu(pta, orc, device, built):
+    """settings.pools = 3: three path pools that borrow one scene and add into one image, driven together by
+    pt_render_run_many.  Every pool traces exactly the rays of the oracle's run of the same share (its own slot base and
+    third of the tickets), the image has exactly spp samples everywhere and the radiance of the three oracle shares
+    added up (float-add order tolerance); reset() + run() reproduces it; a pool context refuses to build scenes."""
+    desc, s, o = built("cornell")
+    w, h, spp, paths, k_pools = 96, 54, 24, 4000, 3
+    pt = pta.init_path_tracer({"device": device, "scene": s, "image": {"width": w, "height": h}, "camera": desc["camera"],
+                               "settings": {"samples": spp, "numPaths": paths, "pools": k_pools}})
+    assert isinstance(pt, pta.host.PooledPathTracer) and len(pt.pools) == k_pools
+    rs = pt.run()
+    img = pt.read_image()
+    total = (w * h * spp + 7) // 8
+    ref = np.zeros((h, w, 4), np.float64); rays = []
+    for k in range(k_pools):
+        orr = orc.OrcRender(o, w, h, desc["camera"], spp, paths, slot_base=k * paths, ticket_begin=total * k // k_pools,
+                            ticket_end=total * (k + 1) // k_pools)
+        steps, n_rays, _ = orr.run()
+        rays.append(n_rays); ref += orr.image()
+        assert pt.last_pool_stats[k].total_rays == n_rays and pt.last_pool_stats[k].steps == steps
+    assert rs.total_rays == sum(rays) and rs.total_samples == w * h * spp
+    np.testing.assert_array_equal(img[..., 3], np.full((h, w), spp, np.float32))
+    np.testing.assert_allclose(img[..., :3], ref[..., :3], rtol=2e-5, atol=1e-5)
+    pt.reset(); rs2 = pt.run()
+    assert rs2.total_rays == rs.total_rays
+    img2 = pt.read_image()
+    np.testing.assert_array_equal(img2[..., 3], img[..., 3])
+    np.testing.assert_allclose(img2[..., :3], img[..., :3], rtol=2e-5, atol=1e-5)
+    with pytest.raises(pta.capi.PtError, match="borrows"):
+        pta.init_scene(pt.pools[1].device).register_mesh(pta.scenes.cornell_box()["meshes"][0])
+    pt.destroy()
