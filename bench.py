@@ -161,7 +161,7 @@ def main():
             "rays_per_render_per_gpu": rays // args.steps, "wavefront_iterations_per_render": int(steps_per_render),
             "scene_build_s": round(build_s, 3),
             "roofline": {"bound": "hbm", "kernel": "k_extend_queue", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(args.config),
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(f"{args.config}_{args.pools}x{args.paths}"),
                          "algorithmic_bytes_per_launch": round(bytes_per_launch, 1),
                          "avg_launch_us": round(avg_s * 1e6, 3), "launches": all_launches, "launches_timed": launches,
                          "extend_share_of_step": round(ext_s / elapsed, 4),
@@ -182,7 +182,7 @@ def main():
 
 def pmc_traffic(config):
     """HBM-side bytes (reads + writes) per extend launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/traffic_<config>.json, written by tools/pmc_traffic.py from TCC_EA0_RDREQ{,_32B,_128B} and WRITE_SIZE); None if absent.
+    (profiles/traffic_<config>_<pools>x<paths>.json, written by tools/pmc_traffic.py from TCC_EA0_RDREQ{,_32B,_128B} and WRITE_SIZE); None if absent.
     PMC counters cannot be collected from inside the timed run, so this is the profiled run's figure."""
     f = os.path.join(ROOT, "profiles", f"traffic_{config}.json")
     if not os.path.exists(f):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turn the `ea` PMC pass (TCC_EA0_RDREQ_sum / _32B_sum / _128B_sum: the L2's memory-side read requests by size)
 into profiles/traffic_<config>.json for bench.py's roofline.traffic.
-    tools/pmc_traffic.py <config> gpurun_out/pmc_<tag>_ea.txt <kernel-name-prefix> [gpurun_out/pmc_<tag>_tcc2.txt]
+    tools/pmc_traffic.py <config>_<pools>x<paths> gpurun_out/pmc_<tag>_ea.txt <kernel-name-prefix> [gpurun_out/pmc_<tag>_tcc2.txt]
 Read bytes = 32*n32 + 128*n128 + 64*(total - n32 - n128); write bytes = WRITE_SIZE (KB, exact for this chip per the
 guide) of the tcc2 pass when that file is given.  (FETCH_SIZE is not used: MI355X_MICROARCH.md notes it tallies
 128-B requests at 64 B for wide streaming reads and is uncalibrated for other widths; the per-size request counters are exact.)"""
