@@ -75,6 +75,16 @@ static napi_value Create(napi_env env, napi_callback_info info) {
     napi_value ext; NAPI_OK(napi_create_external(env, h, finalize_ctx, nullptr, &ext));
     return ext;
 }
+// createSharingScene(ctx) -> context handle that borrows ctx's built scene      [pt_create_sharing_scene]
+static napi_value CreateSharingScene(napi_env env, napi_callback_info info) {
+    napi_value a[1]; if (!get_args(env, info, 1, a)) return nullptr;
+    pt_ctx* src = ctx_of(env, a[0]); if (!src) return nullptr;
+    pt_ctx* c = nullptr; int rc = pt_create_sharing_scene(src, &c);
+    if (rc < 0) return throw_pt(env, src, "pt_create_sharing_scene", rc);
+    pt_ctx** h = new pt_ctx*(c);
+    napi_value ext; NAPI_OK(napi_create_external(env, h, finalize_ctx, nullptr, &ext));
+    return ext;
+}
 // destroy(ctx)                                  [pt_destroy]
 static napi_value Destroy(napi_env env, napi_callback_info info) {
     napi_value a[1]; if (!get_args(env, info, 1, a)) return nullptr;
@@ -155,6 +165,16 @@ static napi_value RenderInit(napi_env env, napi_callback_info info) {
     p.fov_deg = (float)prop(env, a[1], "fov", 60); p.spp = (int32_t)prop(env, a[1], "samples", 8);
     p.num_paths = (int32_t)prop(env, a[1], "numPaths", 0); p.slot_base = (int64_t)prop(env, a[1], "slotBase", 0);
     p.ticket_begin = (int64_t)prop(env, a[1], "ticketBegin", 0); p.ticket_end = (int64_t)prop(env, a[1], "ticketEnd", -1);
+    bool has = false; napi_has_named_property(env, a[1], "imageOf", &has);       // accumulate into another context's image (pools)
+    if (has) {
+        napi_value v; napi_get_named_property(env, a[1], "imageOf", &v);
+        napi_valuetype t; napi_typeof(env, v, &t);
+        if (t == napi_external) {
+            pt_ctx* other = ctx_of(env, v); if (!other) return nullptr;
+            int r2 = pt_image_dev_ptr(other, &p.image_dev);
+            if (r2 < 0) return throw_pt(env, other, "pt_image_dev_ptr", r2);
+        }
+    }
     int rc = pt_render_init(c, &p);
     if (rc < 0) return throw_pt(env, c, "pt_render_init", rc);
     return nullptr;
@@ -209,6 +229,25 @@ static napi_value RenderRun(napi_env env, napi_callback_info info) {
     set(env, o, "extendLaunches", (double)rs.extend_launches); set(env, o, "traversalBytes", (double)rs.traversal_bytes);
     return o;
 }
+// renderRunMany([ctx, ...], maxSteps, flags) -> [stats, ...]                [pt_render_run_many]
+static napi_value RenderRunMany(napi_env env, napi_callback_info info) {
+    napi_value a[3]; if (!get_args(env, info, 3, a)) return nullptr;
+    uint32_t n = 0; napi_get_array_length(env, a[0], &n);
+    if (n < 1 || n > 64) { napi_throw_type_error(env, nullptr, "expected an array of 1..64 contexts"); return nullptr; }
+    pt_ctx* cs[64]; pt_run_stats rs[64];
+    for (uint32_t i = 0; i < n; i++) { napi_value e; napi_get_element(env, a[0], i, &e); cs[i] = ctx_of(env, e); if (!cs[i]) return nullptr; }
+    int rc = pt_render_run_many(cs, (int)n, i64(env, a[1]), (int)i64(env, a[2]), rs);
+    if (rc < 0) return throw_pt(env, cs[0], "pt_render_run_many", rc);
+    napi_value arr; napi_create_array_with_length(env, n, &arr);
+    for (uint32_t i = 0; i < n; i++) {
+        napi_value o; napi_create_object(env, &o);
+        set(env, o, "steps", (double)rs[i].steps); set(env, o, "totalRays", (double)rs[i].total_rays); set(env, o, "totalSamples", (double)rs[i].total_samples);
+        set(env, o, "stackOverflows", (double)rs[i].stack_overflows); set(env, o, "extendMs", rs[i].extend_ms);
+        set(env, o, "extendLaunches", (double)rs[i].extend_launches); set(env, o, "traversalBytes", (double)rs[i].traversal_bytes);
+        napi_set_element(env, arr, i, o);
+    }
+    return arr;
+}
 // imageRead(ctx, Float32Array rgba)                                         [pt_image_read]
 static napi_value ImageRead(napi_env env, napi_callback_info info) {
     napi_value a[2]; if (!get_args(env, info, 2, a)) return nullptr;
@@ -230,7 +269,7 @@ static napi_value Tonemap(napi_env env, napi_callback_info info) {
 
 static napi_value Init(napi_env env, napi_value exports) {
     struct { const char* name; napi_callback fn; } fns[] = {
-        {"create", Create}, {"destroy", Destroy}, {"meshUpload", MeshUpload}, {"sceneBuild", SceneBuild}, {"sceneInfo", SceneInfo},
+        {"create", Create}, {"createSharingScene", CreateSharingScene}, {"renderRunMany", RenderRunMany}, {"destroy", Destroy}, {"meshUpload", MeshUpload}, {"sceneBuild", SceneBuild}, {"sceneInfo", SceneInfo},
         {"readBuffer", ReadBuffer}, {"traceRays", TraceRays}, {"renderInit", RenderInit}, {"renderReset", RenderReset},
         {"renderSetExtensions", RenderSetExtensions},
         {"renderStep", RenderStep}, {"renderRun", RenderRun}, {"imageRead", ImageRead}, {"tonemap", Tonemap}};

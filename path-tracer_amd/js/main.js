@@ -3,7 +3,7 @@
 // (registerMesh x k -> instanceMesh x m -> await build() -> initPathTracer -> initDisplay -> loop { await step(); draw() }),
 // no browser.  The reference's demo meshes (cow / bunny / buddha) are not distributed with it, so the demo scene is
 // the floor it does bundle under a lattice of generated boxes standing in for the 100 instanced meshes (main.js:25-33).
-//   node main.js [--width W] [--height H] [--samples S] [--paths N] [--grid G] [--out frame.png] [--progress K] [--json] [--ext]
+//   node main.js [--width W] [--height H] [--samples S] [--paths N] [--pools K] [--grid G] [--out frame.png] [--progress K] [--json] [--ext]
 // --progress K redraws (rewrites the PNG) every K steps, the headless form of the reference's draw-every-frame loop.
 // --ext switches the extensions on (not in the reference): box i gets material 1 + i % 4, i.e. the reference's dark grey,
 // an orange Lambert, a mirror and a warm emitter; bounce cut at nb > 8; seed 3.
@@ -43,7 +43,7 @@ async function main() {
         device, scene,
         image: { width, height },
         camera: { lookAt: [10, 10, 0], position: [15, 15, 5], fov: 60 },     // main.js:42-46
-        settings: Object.assign({ samples, numPaths: +arg("paths", 0) }, arg("ext", false) ? EXT : {}),
+        settings: Object.assign({ samples, numPaths: +arg("paths", 0), pools: +arg("pools", 1) }, arg("ext", false) ? EXT : {}),
     })
     const display = pt.initDisplay({ device, canvas: arg("out", null), image: { buffer: tracer.getImageBuffer(), width, height } })
 

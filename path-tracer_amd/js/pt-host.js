@@ -138,11 +138,13 @@ function initScene(device) {
 // ---- initPathTracer (path-tracer.js) ----------------------------------------------------------------------------
 function initPathTracer(params) {
     const device = params.device, s = params.settings || {}
+    if ((s.pools || 1) > 1) return initPooledPathTracer(params)
     addon().renderInit(device.ctx, {
         width: params.image.width, height: params.image.height,
         position: params.camera.position, lookAt: params.camera.lookAt, fov: params.camera.fov,
         samples: s.samples, numPaths: s.numPaths || 0, slotBase: s.slotBase || 0,
         ticketBegin: s.ticketBegin || 0, ticketEnd: s.ticketEnd === undefined ? -1 : s.ticketEnd,
+        imageOf: s.imageOf,
     })
     // extensions the reference does not have (default-off): settings.maxNb, settings.seed, settings.materials =
     // [{type: "lambert"|"emitter"|"mirror", albedo: [r,g,b], emission: [r,g,b]}, ...] for material ids 2, 3, ...
@@ -163,6 +165,38 @@ function initPathTracer(params) {
         return out
     }
     return { step, getImageBuffer, run, readImage, reset: () => addon().renderReset(device.ctx) }
+}
+
+// settings.pools = K > 1 (no reference counterpart): K path pools of settings.numPaths slots on one GPU -- contexts that
+// borrow the scene, each with its own stream, RNG streams (slotBase + k * numPaths) and an equal part of the pixel tickets,
+// all adding into pool 0's image, stepped together by renderRunMany (pt_amd.h "several path pools on one GPU").
+function initPooledPathTracer(params) {
+    const s = params.settings, K = s.pools, W = params.image.width, H = params.image.height
+    const numPaths = s.numPaths || 1000000, total = Math.ceil(W * H * s.samples / 8)          // logic.js:177
+    let t0 = s.ticketBegin || 0, t1 = s.ticketEnd === undefined ? -1 : s.ticketEnd
+    if (t1 < 0) { t0 = 0; t1 = total }
+    const pools = []
+    for (let k = 0; k < K; k++) {
+        const dev = k === 0 ? params.device : { ctx: addon().createSharingScene(params.device.ctx) }
+        const sk = Object.assign({}, s, { pools: 1, numPaths, slotBase: (s.slotBase || 0) + k * numPaths,
+            ticketBegin: t0 + Math.floor((t1 - t0) * k / K), ticketEnd: t0 + Math.floor((t1 - t0) * (k + 1) / K),
+            imageOf: k === 0 ? undefined : params.device.ctx })
+        pools.push(Object.assign(initPathTracer(Object.assign({}, params, { device: dev, settings: sk })), { device: dev }))
+    }
+    async function run(maxSteps = 0, flags = 0) {
+        const rs = addon().renderRunMany(pools.map(p => p.device.ctx), maxSteps, flags)
+        const sum = f => rs.reduce((a, r) => a + r[f], 0)
+        return { steps: Math.max(...rs.map(r => r.steps)), totalRays: sum("totalRays"), totalSamples: sum("totalSamples"),
+                 stackOverflows: sum("stackOverflows"), extendMs: sum("extendMs"), extendLaunches: sum("extendLaunches"),
+                 traversalBytes: sum("traversalBytes"), pools: rs }
+    }
+    function readImage() { let img; for (let k = K - 1; k >= 0; k--) img = pools[k].readImage(); return img }   // each read adds that pool's open tickets
+    async function step() {                                                       // every pool takes one step; the sizes add up
+        const r = []; for (const p of pools) r.push(await p.step())
+        const sum = f => r.reduce((a, x) => a + x[f], 0)
+        return { camera: sum("camera"), material: sum("material"), rays: sum("rays"), step: r[0].step, pools: r }
+    }
+    return { step, run, readImage, pools, getImageBuffer: pools[0].getImageBuffer, reset: () => pools.forEach(p => p.reset()) }
 }
 
 // ---- initDisplay (display.js): the canvas is a PNG (or raw RGBA8) ------------------------------------------------

@@ -52,13 +52,13 @@ EXT = {"maxNb": 8, "seed": 3, "materials": [{"type": "lambert", "albedo": [0.8, 
 
 @needs_node
 @pytest.mark.gpu
-@pytest.mark.parametrize("ext", [False, True])
-def test_node_render_equals_python_host_render(pta, device, ext):
+@pytest.mark.parametrize("ext,pools", [(False, 1), (True, 1), (False, 2)])
+def test_node_render_equals_python_host_render(pta, device, ext, pools):
     """main.js (JS host -> N-API -> C ABI) and the Python host drive the same library: identical frames, with the
-    reference's rules and with the extensions (materials, bounce cut, seed) switched on."""
+    reference's rules, with the extensions (materials, bounce cut, seed) switched on, and with two path pools."""
     w, h, spp, paths, grid = 64, 48, 8, 3000, 3
     r = subprocess.run([NODE, "main.js", "--width", str(w), "--height", str(h), "--samples", str(spp), "--paths", str(paths),
-                        "--grid", str(grid), "--json", "--out", "/tmp/node_frame.png"] + (["--ext"] if ext else []),
+                        "--pools", str(pools), "--grid", str(grid), "--json", "--out", "/tmp/node_frame.png"] + (["--ext"] if ext else []),
                        cwd=JS, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout + r.stderr
     rep = json.loads(r.stdout.strip().splitlines()[-1])
@@ -72,7 +72,7 @@ def test_node_render_equals_python_host_render(pta, device, ext):
     scene.build()
     pt = pta.init_path_tracer({"device": device, "scene": scene, "image": {"width": w, "height": h},
                                "camera": {"lookAt": [10, 10, 0], "position": [15, 15, 5], "fov": 60},
-                               "settings": dict({"samples": spp, "numPaths": paths}, **(EXT if ext else {}))})
+                               "settings": dict({"samples": spp, "numPaths": paths, "pools": pools}, **(EXT if ext else {}))})
     rs = pt.run()
     img = pt.read_image()
     assert rep["steps"] == rs.steps and rep["rays"] == rs.total_rays
