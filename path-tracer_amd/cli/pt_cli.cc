@@ -2,7 +2,7 @@
 // (registerMesh x k -> instanceMesh x m -> build -> initPathTracer -> loop { step } -> display) in C++ over the C ABI.
 //
 //   pt_cli [--obj FILE]... [--instance MESH,px,py,pz,rx,ry,rz,sx,sy,sz,MATERIAL]... [--camera px,py,pz,lx,ly,lz,fov]
-//          [--width W] [--height H] [--samples S] [--paths N] [--device D] [--progress K] [--out frame.png|frame.ppm] [--json]
+//          [--width W] [--height H] [--samples S] [--paths N] [--pools K] [--device D] [--progress K] [--out frame.png|frame.ppm] [--json]
 //   pt_cli --dump-host FILE px,py,pz,rx,ry,rz,sx,sy,sz      host-side results only (no GPU): parse + matrices + world box as JSON
 //
 // Without --obj the scene is the reference's bundled floor with its main.js:33 instance and main.js:42-46 camera.
@@ -98,7 +98,7 @@ static int dump_host(const std::string& file, const std::string& trs) {
 
 int main(int argc, char** argv) {
     std::vector<std::string> objs, insts; std::string cam, out; bool json = false;
-    int width = 512, height = 512, samples = 16, paths = 0, device = 0, progress = 0;
+    int width = 512, height = 512, samples = 16, paths = 0, device = 0, progress = 0, pools = 1;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto next = [&]() -> std::string { return i + 1 < argc ? argv[++i] : ""; };
@@ -110,6 +110,7 @@ int main(int argc, char** argv) {
         else if (a == "--height") height = atoi(next().c_str());
         else if (a == "--samples") samples = atoi(next().c_str());
         else if (a == "--paths") paths = atoi(next().c_str());
+        else if (a == "--pools") pools = std::max(1, atoi(next().c_str()));
         else if (a == "--device") device = atoi(next().c_str());
         else if (a == "--progress") progress = atoi(next().c_str());
         else if (a == "--out") out = next();
@@ -153,12 +154,24 @@ int main(int argc, char** argv) {
     pt_render_params rp; memset(&rp, 0, sizeof rp);
     rp.width = width; rp.height = height; rp.spp = samples; rp.num_paths = paths; rp.ticket_end = -1; rp.fov_deg = (float)c[6];
     for (int k = 0; k < 3; k++) { rp.cam_pos[k] = (float)c[k]; rp.cam_look_at[k] = (float)c[3 + k]; }
-    CHECK(pt_render_init(ctx, &rp));
+    // --pools K > 1 (no reference counterpart, pt_amd.h "several path pools on one GPU"): K contexts that borrow the scene,
+    // pool k with its own RNG streams and the k-th part of the pixel tickets, all adding into pool 0's image
+    std::vector<pt_ctx*> pool{ctx};
+    const long long per_pool = paths > 0 ? paths : 1000000, total = ((long long)width * height * samples + 7) / 8;   // logic.js:177
+    for (int k = 0; k < pools; k++) {
+        if (k > 0) { pt_ctx* c2 = nullptr; CHECK(pt_create_sharing_scene(ctx, &c2)); pool.push_back(c2); }
+        if (pools > 1) {
+            rp.num_paths = (int32_t)per_pool; rp.slot_base = k * per_pool; rp.ticket_begin = total * k / pools; rp.ticket_end = total * (k + 1) / pools;
+            if (k > 0) CHECK(pt_image_dev_ptr(ctx, &rp.image_dev));
+        }
+        CHECK(pt_render_init(pool[k], &rp));
+    }
 
     std::vector<uint8_t> rgba((size_t)width * height * 4);
     long long steps = 0, rays = 0; int frames = 0;
     for (;;) {                                                                    // main.js:61-72, stopping on empty queues
-        pt_step_stats st; CHECK(pt_render_step(ctx, &st));
+        pt_step_stats st; memset(&st, 0, sizeof st);
+        for (pt_ctx* pc : pool) { pt_step_stats s1; CHECK(pt_render_step(pc, &s1)); st.n_rays += s1.n_rays; st.n_camera += s1.n_camera; st.n_material += s1.n_material; }
         steps++; rays += st.n_rays;
         bool done = st.n_camera + st.n_material == 0;
         if (!out.empty() && (done || (progress > 0 && steps % progress == 0))) {
@@ -169,12 +182,13 @@ int main(int argc, char** argv) {
         if (done) break;
     }
     std::vector<float> img((size_t)width * height * 4);
-    CHECK(pt_image_read(ctx, img.data(), (int64_t)img.size()));
+    for (int k = pools - 1; k >= 0; k--) CHECK(pt_image_read(pool[k], img.data(), (int64_t)img.size()));   // each read adds that pool's open tickets
     double wsum = 0, rsum = 0; for (size_t i = 0; i < (size_t)width * height; i++) { wsum += img[4 * i + 3]; rsum += img[4 * i]; }
     if (json) printf("{\"width\": %d, \"height\": %d, \"samples\": %d, \"steps\": %lld, \"rays\": %lld, \"sampleCount\": %.17g, \"radianceSum\": %.17g, "
                      "\"nTris\": %lld, \"nObjects\": %d, \"frames\": %d}\n", width, height, samples, steps, rays, wsum, rsum, (long long)si.n_tris, si.n_objects, frames);
     else printf("%dx%d, %d spp: %lld steps, %lld rays, %lld triangles in %d instances%s%s\n", width, height, samples, steps, rays,
                 (long long)si.n_tris, si.n_objects, out.empty() ? "" : " -> ", out.c_str());
+    for (int k = pools - 1; k > 0; k--) pt_destroy(pool[k]);
     pt_destroy(ctx);
     return 0;
 }

@@ -73,20 +73,21 @@ def read_png(path):
 
 
 @pytest.mark.gpu
-def test_cli_render_equals_python_host_render(cli, pta, device, tmp_path):
+@pytest.mark.parametrize("pools", [1, 2])
+def test_cli_render_equals_python_host_render(cli, pta, device, tmp_path, pools):
     """pt_cli (C++ host -> C ABI) renders the reference's floor scene (main.js:33,42-46); the Python host renders the same:
     identical step / ray / sample counts; radiance to the float-add-order tolerance (--progress draws mid-render, which
     adds the unfinished tickets' partial sums early and so reorders the adds), PNG pixels within one 8-bit step."""
     w, h, spp, paths = 64, 48, 8, 3000
     out = tmp_path / "frame.png"
-    r = subprocess.run([cli, "--width", str(w), "--height", str(h), "--samples", str(spp), "--paths", str(paths), "--json",
+    r = subprocess.run([cli, "--width", str(w), "--height", str(h), "--samples", str(spp), "--paths", str(paths), "--pools", str(pools), "--json",
                         "--progress", "3", "--out", str(out)], capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout + r.stderr
     rep = json.loads(r.stdout.strip().splitlines()[-1])
     desc = pta.scenes.floor_scene()
     s = pta.scenes.populate(pta.init_scene(device), desc); s.build()
     pt = pta.init_path_tracer({"device": device, "scene": s, "image": {"width": w, "height": h}, "camera": desc["camera"],
-                               "settings": {"samples": spp, "numPaths": paths}})
+                               "settings": {"samples": spp, "numPaths": paths, "pools": pools}})
     rs = pt.run()
     img = pt.read_image()
     assert (rep["steps"], rep["rays"], rep["nTris"], rep["nObjects"]) == (rs.steps, rs.total_rays, 2, 1)
