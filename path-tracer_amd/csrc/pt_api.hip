@@ -42,6 +42,7 @@ struct pt_ctx {
     float* d_image = nullptr; bool own_image = false; uint8_t* d_code = nullptr;
     int4 *d_blk_counts = nullptr; int32_t *d_cam_q = nullptr, *d_mat_q = nullptr, *d_spill = nullptr;
     StepHeader* d_hdr = nullptr; StepHeader* h_hdr = nullptr; int nblocks = 0; int64_t step = 0;
+    bool overlapped = false;    // the last pt_render_run_many drove this context together with others
     int64_t known_rays = -1;    // queue size in the last header the host has seen (-1: none yet); picks the compaction kernel's shape
     float4* d_ext_mats = nullptr; int n_ext_mats = 0;   // extension materials (pt_render_set_extensions)
     float4* d_wide = nullptr; int traversal_mode = 0;   // fast mode (pt_set_traversal_mode): 4-wide collapse of the packed BLAS
@@ -195,8 +196,12 @@ void enqueue_step(pt_ctx* c, int count_visits, hipEvent_t ev0, hipEvent_t ev1) {
     int parity = (int)(c->step & 1);
     if (c->step == 0) ptk_first_logic(c->ps, c->rc, c->d_code, c->stream);
     // One compaction workgroup per count record while the step has little to do -- the first steps (camera rays only) and
-    // the ramp-down, as far as the host knows it (pt_render_run sees headers up to two batches late) -- else four.
-    int fat = c->step < 6 || (c->known_rays >= 0 && 2 * c->known_rays < c->rc.num_paths);
+    // the ramp-down, as far as the host knows it (pt_render_run sees headers up to two batches late) -- else four.  When
+    // several pools run together (pt_render_run_many) always one: the other pools' launches hide this one's latencies,
+    // so the shape that does less work wins (+2 %).
+    int fat = c->overlapped || c->step < 6 || (c->known_rays >= 0 && 2 * c->known_rays < c->rc.num_paths);
+    static const int shape = getenv("PT_COMPACT_SHAPE") ? atoi(getenv("PT_COMPACT_SHAPE")) : 0;   // measurement: 1 = always four per record, 2 = always one
+    if (shape) fat = shape == 2;
     ptk_count_compact_generate_shade(c->ps, c->rc, sv, c->d_code, c->d_blk_counts, parity, c->d_hdr, c->d_cam_q, c->d_mat_q, fat, c->stream);
     if (ev0) (void)hipEventRecord(ev0, c->stream);
     ptk_extend_queue(c->ps, c->rc, sv, c->d_hdr, c->d_cam_q, c->d_mat_q, c->d_spill, count_visits, c->extend_variant, nullptr, c->d_image, c->d_code, c->stream);
@@ -583,6 +588,7 @@ int pt_render_run_many(pt_ctx** ctxs, int n, int64_t max_steps, int flags, pt_ru
     int r;
     for (int i = 0; i < n; i++) {
         pt_ctx* c = rs[i].c = ctxs[i];
+        c->overlapped = n > 1;
         if (c->events.empty()) {   // per batch parity: [0,1] bracket a timed extend launch, [2] marks "header copy landed"
             c->events.resize(6);
             for (hipEvent_t& e : c->events) HIPOK(c, hipEventCreate(&e));
