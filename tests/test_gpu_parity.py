@@ -594,4 +594,8 @@ def test_pools_on_one_gpu(pta, orc, device, built):
     np.testing.assert_allclose(img2[..., :3], img[..., :3], rtol=2e-5, atol=1e-5)
     with pytest.raises(pta.capi.PtError, match="borrows"):
         pta.init_scene(pt.pools[1].device).register_mesh(pta.scenes.cornell_box()["meshes"][0])
+    import ctypes as C
+    twice = (C.c_void_p * 2)(pt.pools[1].device.ctx, pt.pools[1].device.ctx)
+    assert device.lib.pt_render_run_many(twice, 2, 0, 0, None) == -1          # PT_ERR_ARG
+    assert b"twice" in device.lib.pt_last_error(pt.pools[1].device.ctx)
     pt.destroy()
