@@ -5,7 +5,7 @@
 
 Metric (BASELINE.json): Mrays/s at 1920x1080.  Workload at N=1: configs[1], the Cornell box at 1920x1080,
 64 spp, 3 path pools of 750,000 slots in flight (--pools, --paths; the reference has one pool of NUM_PATHS = 1,000,000).
-One "step" = one complete render of that frame: every wavefront iteration (count -> compact+generate+shade -> extend+logic) until both
+One "step" = one complete render of that frame: every wavefront iteration (compact+generate+shade -> extend+logic) until both
 stage-2 queues are empty, with the scene and all buffers already resident in HBM.  N > 1: one process per GPU (torchrun),
 each GPU renders the full 64 spp with its own RNG streams (slot_base = (rank * pools + pool) * NUM_PATHS) and its own ticket
 range, i.e. the node accumulates N*64 spp ("weak": per-GPU work fixed); the per-GPU accumulation buffers are

@@ -194,7 +194,7 @@ int read_back(pt_ctx* c, void* dst, const void* src, size_t bytes) {
 void enqueue_step(pt_ctx* c, int count_visits, hipEvent_t ev0, hipEvent_t ev1) {
     SceneView sv = scene_view(c);
     int parity = (int)(c->step & 1);
-    if (c->step == 0) ptk_first_logic(c->ps, c->rc, c->d_code, c->stream);
+    if (c->step == 0) ptk_first_logic(c->ps, c->rc, c->d_code, c->d_blk_counts, c->stream);
     // One compaction workgroup per count record while the step has little to do -- the first steps (camera rays only) and
     // the ramp-down, as far as the host knows it (pt_render_run sees headers up to two batches late) -- else four.  When
     // several pools run together (pt_render_run_many) always one: the other pools' launches hide this one's latencies,
@@ -204,7 +204,8 @@ void enqueue_step(pt_ctx* c, int count_visits, hipEvent_t ev0, hipEvent_t ev1) {
     if (shape) fat = shape == 2;
     ptk_count_compact_generate_shade(c->ps, c->rc, sv, c->d_code, c->d_blk_counts, parity, c->d_hdr, c->d_cam_q, c->d_mat_q, fat, c->stream);
     if (ev0) (void)hipEventRecord(ev0, c->stream);
-    ptk_extend_queue(c->ps, c->rc, sv, c->d_hdr, c->d_cam_q, c->d_mat_q, c->d_spill, count_visits, c->extend_variant, nullptr, c->d_image, c->d_code, c->stream);
+    ptk_extend_queue(c->ps, c->rc, sv, c->d_hdr, c->d_cam_q, c->d_mat_q, c->d_spill, count_visits, c->extend_variant, nullptr, c->d_image, c->d_code,
+                     (unsigned long long*)c->d_blk_counts + (parity ^ 1), c->stream);
     if (ev1) (void)hipEventRecord(ev1, c->stream);
     c->step++;
 }
@@ -729,7 +730,7 @@ int pt_extend_replay(pt_ctx* c, int variant, int reps, double* avg_us) {
     double total_ms = 0;
     for (int i = 0; i < reps; i++) {   // the kernel only reads path_o/path_d and rewrites the same hit_obj/hit_tri: idempotent
         HIPOK(c, hipEventRecord(e0, c->stream));
-        ptk_extend_queue(c->ps, c->rc, sv, c->d_hdr, c->d_cam_q, c->d_mat_q, c->d_spill, 0, variant, nullptr, nullptr, nullptr, c->stream);
+        ptk_extend_queue(c->ps, c->rc, sv, c->d_hdr, c->d_cam_q, c->d_mat_q, c->d_spill, 0, variant, nullptr, nullptr, nullptr, nullptr, c->stream);
         HIPOK(c, hipEventRecord(e1, c->stream));
         HIPOK(c, hipEventSynchronize(e1));
         float ms = 0; HIPOK(c, hipEventElapsedTime(&ms, e0, e1)); total_ms += ms;
@@ -749,7 +750,7 @@ int pt_extend_wave_log(pt_ctx* c, int variant, uint64_t* out, int64_t cap_waves,
     unsigned long long* d_log = nullptr; int r; Tmp tmp;
     if ((r = tmp.alloc(c, &d_log, (size_t)n * 4, true))) return r;
     SceneView sv = scene_view(c);
-    ptk_extend_queue(c->ps, c->rc, sv, c->d_hdr, c->d_cam_q, c->d_mat_q, c->d_spill, 0, variant, d_log, nullptr, nullptr, c->stream);
+    ptk_extend_queue(c->ps, c->rc, sv, c->d_hdr, c->d_cam_q, c->d_mat_q, c->d_spill, 0, variant, d_log, nullptr, nullptr, nullptr, c->stream);
     HIPOK(c, hipGetLastError());
     r = read_back(c, out, d_log, (size_t)n * 32);
     *n_waves = n;

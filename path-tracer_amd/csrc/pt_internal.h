@@ -113,16 +113,19 @@ hipError_t pt_sort_pairs_u32(void* tmp, size_t* tmp_bytes, const uint32_t* kin, 
 
 // ---- launchers (pt_kernels_render.hip) --------------------------------------------------------
 int  ptk_step_blocks(int num_paths);   // count records per step; the code array holds PT_STEP_BLOCK bytes per record, zero padded
-void ptk_first_logic(const PathState& ps, const RenderConst& rc, uint8_t* code, hipStream_t s);   // before step 0 only
+// blk_counts: per PT_STEP_BLOCK slots two 64-bit count records {#camera | #material << 16 | #tickets << 32 | #finished << 48},
+// [step & 1] read by that step's compaction, the other filled by its extend launch (first_logic writes step 0's)
+void ptk_first_logic(const PathState& ps, const RenderConst& rc, uint8_t* code, int4* blk_counts, hipStream_t s);   // before step 0 only
 // counts -> queues, tickets, camera rays, StepHeader.  parity = step & 1 (StepHeader::ticket_next)
 void ptk_count_compact_generate_shade(const PathState& ps, const RenderConst& rc, const SceneView& sc, const uint8_t* code, int4* blk_counts, int parity, StepHeader* hdr,
                                 int32_t* cam_q, int32_t* mat_q, int fat /* one workgroup per count record: for steps with few live slots */, hipStream_t s);
 // Extend over the step's ray queue (camera ++ material), followed per slot by the next step's logic and material sample
-// (code != null; they write the decision codes the next ptk_count_compact_generate reads).  code == null: traversal only.
+// (code != null; they write the decision codes and count records the next ptk_count_compact_generate_shade reads).  code == null: traversal only.
 // count != 0 selects the visit-counting variant.
 void ptk_extend_queue(const PathState& ps, const RenderConst& rc, const SceneView& sc, StepHeader* hdr,
                       const int32_t* cam_q, const int32_t* mat_q, int32_t* spill, int count, int variant,
-                      unsigned long long* wave_log /* null unless measuring */, float* image, uint8_t* code, hipStream_t s);   // uses rc.max_nb
+                      unsigned long long* wave_log /* null unless measuring */, float* image, uint8_t* code,
+                      unsigned long long* rec_next /* the next step's count records, used with code */, hipStream_t s);   // uses rc.max_nb
 int64_t ptk_extend_waves(int num_paths, int variant);   // waves the launch of that variant holds (wave_log entries)
 int ptk_extend_num_variants();
 const char* ptk_extend_variant_name(int v);

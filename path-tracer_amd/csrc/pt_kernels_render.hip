@@ -1,6 +1,6 @@
 // pt_kernels_render.hip -- the wavefront integrator on gfx950 (extend is in pt_kernels_extend.hip).
 //
-// One step() = count -> compact+generate+shade -> extend(+logic): three launches on one stream, no host round trip in
+// One step() = compact+generate+shade -> extend(+logic, + the next step's count records): two launches on one stream, no host round trip in
 // between (the reference awaits the queue after each of its four dispatches, path-tracer.js:86-107).  The launch
 // that compacts the slots also produces their next rays: the camera ray as soon as the pixel ticket is known, or
 // the bounce ray (the camera and material kernels only touch their slot's own state); the thread that traced a slot's
@@ -25,9 +25,13 @@ __device__ __forceinline__ int4 add4(int4 a, int4 b) { return make_int4(a.x + b.
 // first logic (logic.js:72-80): the step-0 branch -- seed the slot's random stream, ask for a camera ray and a ticket.
 // Every later logic pass runs in the tail of the extend kernel (pt_kernels_extend.hip).
 // ============================================================================================
-__global__ __launch_bounds__(PT_BLOCK) void k_first_logic(PathState ps, RenderConst rc, uint8_t* __restrict__ code_out) {
+__global__ __launch_bounds__(PT_BLOCK) void k_first_logic(PathState ps, RenderConst rc, uint8_t* __restrict__ code_out, unsigned long long* __restrict__ rec0) {
     int i = blockIdx.x * PT_BLOCK + threadIdx.x;
     if (i >= rc.num_paths) return;
+    if (i % PT_STEP_BLOCK == 0) {                                          // step 0's count record: every slot wants a camera ray and a ticket
+        unsigned long long n = (unsigned long long)min(PT_STEP_BLOCK, rc.num_paths - i);
+        rec0[2 * (i / PT_STEP_BLOCK)] = n | (n << 32);
+    }
     uint32_t gi = (uint32_t)(rc.slot_base + i) + rc.seed_mix;              // seed_mix: 0 unless the seed extension is set
     ps.random_seed[i] = (float)base_hash(gi, gi + 1u) * 2.3283064365386962890625e-10f + 0.008f;   // logic.js:77
     ps.path_throughput[i] = mk3(1.0f, 1.0f, 1.0f);
@@ -35,31 +39,12 @@ __global__ __launch_bounds__(PT_BLOCK) void k_first_logic(PathState ps, RenderCo
 }
 
 // ============================================================================================
-// count: one record {#camera, #material, #tickets, #finished samples} per PT_STEP_BLOCK slots, from the decision codes
-// (four codes per 32-bit load; the code array is padded with zeros to a whole record).
-// ============================================================================================
-__global__ __launch_bounds__(PT_BLOCK) void k_count(const uint32_t* __restrict__ code4, int4* __restrict__ blk_counts) {
-    __shared__ int4 s_wave[PT_BLOCK / 64];
-    static_assert(PT_STEP_BLOCK == 4 * PT_BLOCK, "one 32-bit load of four codes per thread");
-    uint32_t w = code4[blockIdx.x * PT_BLOCK + threadIdx.x];
-    int4 c = make_int4(__popc(w & 0x01010101u), __popc(w & 0x02020202u), __popc(w & 0x04040404u), __popc(w & 0x08080808u));
-    for (int off = 32; off > 0; off >>= 1)
-        c = add4(c, make_int4(__shfl_xor(c.x, off), __shfl_xor(c.y, off), __shfl_xor(c.z, off), __shfl_xor(c.w, off)));
-    if (lane_id() == 0) s_wave[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int4 t = s_wave[0];
-        for (int k = 1; k < PT_BLOCK / 64; k++) t = add4(t, s_wave[k]);
-        blk_counts[blockIdx.x] = t;
-    }
-}
-
-// ============================================================================================
 // compact + generate + shade: stable scatter into the camera / material queues and pixel tickets (logic.js:155-219),
 // then the slots' next rays by the same workgroup -- the camera ray of a slot that starts a sample (camera.js:60-118) or
 // the bounce ray of a slot that continues (material.js:75-120); both only touch that slot's own state, so neither
 // waits for a queue.  Workgroup 0 also closes the step's books in the StepHeader.
-// No scan launch: k_count leaves one record per 1024 slots (~1000 per step); a workgroup here adds up the records in
+// No scan and no counting launch: the extend kernel's logic tail leaves one count record per 1024 slots (64-bit atomics,
+// two buffers alternating between steps; this launch clears the one the coming extend launch fills); a workgroup here adds up the records in
 // front of its 1024-slot group (<= 4 16-B loads per thread, L2 resident) and, when it is one of four per group,
 // re-counts the codes of the <= 3 workgroups in front of it inside the group.  Measured alternatives: a one-workgroup scan launch (9 us of
 // pure latency per step), "last logic workgroup to arrive scans" (+100 us of contended arrivals), per-64-workgroup
@@ -77,7 +62,7 @@ __device__ __forceinline__ int4 wave_sum4(int4 v) {
 }
 template <int PL>
 __global__ __launch_bounds__(PT_BLOCK) void k_compact_generate_shade(PathState ps, RenderConst rc, SceneView sc, const uint8_t* __restrict__ code_in,
-                                                                     const int4* __restrict__ blk_counts, int nrecords, int parity, StepHeader* hdr,
+                                                                     unsigned long long* __restrict__ rec, int nrecords, int parity, StepHeader* hdr,
                                                                      int32_t* __restrict__ cam_q, int32_t* __restrict__ mat_q) {
     // A workgroup takes PL planes of 256 consecutive slots (plane-major = slot order).  PL = 1: four workgroups per count
     // record, the shortest launch while the pool is full (6 waves per SIMD, one body per thread); PL = 4: one workgroup per
@@ -105,7 +90,11 @@ __global__ __launch_bounds__(PT_BLOCK) void k_compact_generate_shade(PathState p
     {   // counts in front of this workgroup; workgroup 0 adds up all records for the header
         const int upto = b == 0 ? nrecords : group;
         int4 acc = make_int4(0, 0, 0, 0);
-        for (int j = threadIdx.x; j < upto; j += PT_BLOCK) acc = add4(acc, blk_counts[j]);
+        for (int j = threadIdx.x; j < upto; j += PT_BLOCK) {
+            unsigned long long v = rec[2 * j + parity];
+            acc = add4(acc, make_int4((int)(v & 0xffffu), (int)((v >> 16) & 0xffffu), (int)((v >> 32) & 0xffffu), (int)(v >> 48)));
+        }
+        if (sub == 0 && threadIdx.x == 0) rec[2 * group + (parity ^ 1)] = 0ull;       // filled by the extend launch that follows
         for (int k = 0; k < sub * PL; k++) {                    // the planes of this record in front of this workgroup
             unsigned c = code_in[group * PT_STEP_BLOCK + k * PT_BLOCK + threadIdx.x];
             acc.x += c & 1u; acc.y += (c >> 1) & 1u; acc.z += (c >> 2) & 1u;
@@ -207,15 +196,14 @@ __global__ __launch_bounds__(PT_BLOCK) void k_tonemap(const float4* __restrict__
 __global__ void k_camera_frame(RenderConst rc, CameraFrame* out) { *out = camera_frame(rc); }
 void ptk_camera_frame(const RenderConst& rc, CameraFrame* out_dev, hipStream_t s) { hipLaunchKernelGGL(k_camera_frame, dim3(1), dim3(1), 0, s, rc, out_dev); }
 int ptk_step_blocks(int num_paths) { return (num_paths + PT_STEP_BLOCK - 1) / PT_STEP_BLOCK; }
-void ptk_first_logic(const PathState& ps, const RenderConst& rc, uint8_t* code, hipStream_t s) {
-    hipLaunchKernelGGL(k_first_logic, grid_for(rc.num_paths), dim3(PT_BLOCK), 0, s, ps, rc, code);
+void ptk_first_logic(const PathState& ps, const RenderConst& rc, uint8_t* code, int4* blk_counts, hipStream_t s) {
+    hipLaunchKernelGGL(k_first_logic, grid_for(rc.num_paths), dim3(PT_BLOCK), 0, s, ps, rc, code, (unsigned long long*)blk_counts);
 }
 void ptk_count_compact_generate_shade(const PathState& ps, const RenderConst& rc, const SceneView& sc, const uint8_t* code, int4* blk_counts, int parity, StepHeader* hdr,
                                 int32_t* cam_q, int32_t* mat_q, int fat, hipStream_t s) {
     int nrecords = ptk_step_blocks(rc.num_paths);
-    hipLaunchKernelGGL(k_count, dim3(nrecords), dim3(PT_BLOCK), 0, s, (const uint32_t*)code, blk_counts);
-    if (fat) hipLaunchKernelGGL(k_compact_generate_shade<PT_STEP_BLOCK / PT_BLOCK>, dim3(nrecords), dim3(PT_BLOCK), 0, s, ps, rc, sc, code, blk_counts, nrecords, parity, hdr, cam_q, mat_q);
-    else hipLaunchKernelGGL(k_compact_generate_shade<1>, grid_for(rc.num_paths), dim3(PT_BLOCK), 0, s, ps, rc, sc, code, blk_counts, nrecords, parity, hdr, cam_q, mat_q);
+    if (fat) hipLaunchKernelGGL(k_compact_generate_shade<PT_STEP_BLOCK / PT_BLOCK>, dim3(nrecords), dim3(PT_BLOCK), 0, s, ps, rc, sc, code, (unsigned long long*)blk_counts, nrecords, parity, hdr, cam_q, mat_q);
+    else hipLaunchKernelGGL(k_compact_generate_shade<1>, grid_for(rc.num_paths), dim3(PT_BLOCK), 0, s, ps, rc, sc, code, (unsigned long long*)blk_counts, nrecords, parity, hdr, cam_q, mat_q);
 }
 void ptk_flush_tickets(const PathState& ps, int num_paths, float* image, hipStream_t s) {
     hipLaunchKernelGGL(k_flush_tickets, grid_for(num_paths), dim3(PT_BLOCK), 0, s, ps, num_paths, image);
