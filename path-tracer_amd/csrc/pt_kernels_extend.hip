@@ -219,7 +219,7 @@ template <int LDS_N, int BLOCK, bool COUNT, int ORDER, bool LOG, bool LOGIC, boo
 __global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView sc, StepHeader* hdr, const int32_t* __restrict__ cam_q,
                                                         const int32_t* __restrict__ mat_q, int32_t* spill, int64_t spill_stride,
                                                         unsigned long long* wave_log, float* __restrict__ image, uint8_t* __restrict__ code_out,
-                                                        unsigned long long* __restrict__ rec_next, int max_nb) {
+                                                        unsigned long long* __restrict__ rec_next, RenderConst rc) {
     unsigned long long t_start = LOG ? wall_clock64() : 0;
     __shared__ int s_stack[LDS_N * BLOCK];
     int n_cam = hdr->n_camera, n_rays = n_cam + hdr->n_material;
@@ -246,14 +246,17 @@ __global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView 
     unsigned code = 0u; int grp = -1;
     if (q < n_rays) {
         int path = q < n_cam ? cam_q[q] : mat_q[q - n_cam];
-        ray_init(r, F3(ps.path_o[path]), F3(ps.path_d[path]));
+        f3 ro, rd;
+        if (LOGIC && q < n_cam) generate_one(ps, rc, path, ro, rd);          // camera.js:60-118; replays (no LOGIC) re-read the stored ray
+        else { ro = F3(ps.path_o[path]); rd = F3(ps.path_d[path]); }
+        ray_init(r, ro, rd);
         typedef Stack<LDS_N, BLOCK, SHALLOW> STK;
         STK stk{s_stack + threadIdx.x, spill + q, spill_stride};
         while (trav_step<COUNT, STK, WIDE>(sc, r, stk)) {}
         trav_finish<COUNT>(sc, r);
         ps.hit[path] = make_int2(r.hit_obj, r.hit_tri);
         if (LOGIC) {
-            code = logic_one(ps, image, path, r.hit_obj >= 0, max_nb);
+            code = logic_one(ps, image, path, r.hit_obj >= 0, rc.max_nb);
             code_out[path] = (uint8_t)code;
             grp = path / PT_STEP_BLOCK;
         }
@@ -324,12 +327,12 @@ size_t ptk_spill_ints(int64_t n_rays) { return (size_t)pad_to(n_rays, 256) * (PT
 template <int LDS_N, int BLOCK, int ORDER, bool WIDE = false, int SCENE_QUADS = 0, bool SHALLOW = false>
 static void launch_queue(const PathState& ps, int num_paths, const SceneView& sc, StepHeader* hdr, const int32_t* cam_q,
                          const int32_t* mat_q, int32_t* spill, int count, unsigned long long* wave_log, float* image, uint8_t* code,
-                         unsigned long long* rec_next, int max_nb, hipStream_t s) {
+                         unsigned long long* rec_next, const RenderConst& rc, hipStream_t s) {
     int64_t stride = pad_to(num_paths, 256);
     dim3 grid((unsigned)((num_paths + BLOCK - 1) / BLOCK));
     const size_t scene_lds = SCENE_QUADS > 0 ? 16 * (size_t)(12 * sc.n_objects + 7 * sc.n_tris) : 0;
 #define PT_LAUNCH(COUNT, LOG, LOGIC) hipLaunchKernelGGL((k_extend_queue<LDS_N, BLOCK, COUNT, ORDER, LOG, LOGIC, WIDE, SCENE_QUADS, SHALLOW>), grid, dim3(BLOCK), scene_lds, s, ps, sc, hdr, \
-                                                       cam_q, mat_q, spill, stride, wave_log, image, code, rec_next, max_nb)
+                                                       cam_q, mat_q, spill, stride, wave_log, image, code, rec_next, rc)
     if (wave_log)    PT_LAUNCH(false, true, false);    // measurement replays (code == null): traversal only, idempotent
     else if (!code)  PT_LAUNCH(false, false, false);
     else if (count)  PT_LAUNCH(true, false, true);
@@ -358,16 +361,16 @@ const char* ptk_extend_variant_name(int v) { return (v >= 0 && v < 4) ? kVariant
 void ptk_extend_queue(const PathState& ps, const RenderConst& rc, const SceneView& sc, StepHeader* hdr, const int32_t* cam_q,
                       const int32_t* mat_q, int32_t* spill, int count, int variant, unsigned long long* wave_log, float* image, uint8_t* code,
                       unsigned long long* rec_next, hipStream_t s) {
-    if (sc.wide)           launch_queue<16, 64, 2, true>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc.max_nb, s);   // fast mode
-    else if (variant == 0) launch_queue<24, 256, 1>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc.max_nb, s);
-    else if (variant == 1) launch_queue<16, 64, 1>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc.max_nb, s);
+    if (sc.wide)           launch_queue<16, 64, 2, true>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);   // fast mode
+    else if (variant == 0) launch_queue<24, 256, 1>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
+    else if (variant == 1) launch_queue<16, 64, 1>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
     else if (variant == 3 && 12 * (int64_t)sc.n_objects + 7 * (int64_t)sc.n_tris <= PT_SCENE_LDS_QUADS) {
         if (sc.stack_bound <= PT_STAGED_LDS_STACK)      // no ray's stack can leave LDS: no spill path, no overflow guard
-            launch_queue<PT_STAGED_LDS_STACK, 256, 2, false, PT_SCENE_LDS_QUADS, true>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc.max_nb, s);
+            launch_queue<PT_STAGED_LDS_STACK, 256, 2, false, PT_SCENE_LDS_QUADS, true>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
         else
-            launch_queue<PT_STAGED_LDS_STACK, 256, 2, false, PT_SCENE_LDS_QUADS>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc.max_nb, s);
+            launch_queue<PT_STAGED_LDS_STACK, 256, 2, false, PT_SCENE_LDS_QUADS>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
     }
-    else                   launch_queue<16, 64, 2>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc.max_nb, s);
+    else                   launch_queue<16, 64, 2>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
 }
 int64_t ptk_extend_waves(int num_paths, int variant) {
     int block = (variant == 0 || variant == 3) ? 256 : 64;   // variant 3 falls back to 64 when the scene does not fit: an upper bound then

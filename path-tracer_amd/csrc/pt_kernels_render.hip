@@ -1,10 +1,11 @@
 // pt_kernels_render.hip -- the wavefront integrator on gfx950 (extend is in pt_kernels_extend.hip).
 //
-// One step() = compact+generate+shade -> extend(+logic, + the next step's count records): two launches on one stream, no host round trip in
+// One step() = compact+shade -> generate+extend(+logic, + the next step's count records): two launches on one stream, no host round trip in
 // between (the reference awaits the queue after each of its four dispatches, path-tracer.js:86-107).  The launch
-// that compacts the slots also produces their next rays: the camera ray as soon as the pixel ticket is known, or
-// the bounce ray (the camera and material kernels only touch their slot's own state); the thread that traced a slot's
-// ray runs the slot's logic for the next step (pt_kernels_extend.hip).
+// that compacts the slots also samples the materials of the slots that continue (their bounce rays); the extend launch
+// makes the camera ray of every camera-queue entry and traces it at once, and the thread that traced a slot's ray runs
+// the slot's logic for the next step (pt_kernels_extend.hip).  The camera, material and logic kernels only touch their
+// slot's own state, which is what makes the regrouping legal.
 // Queue appends are order-preserving: wave64 ballots give each lane its rank, the count records in front of a
 // workgroup give it its base (no scan launch), so every queue is in ascending path-slot order and pixel tickets are
 // handed out in slot order (the reference's canonical serial order; its own order is a race,
@@ -39,10 +40,9 @@ __global__ __launch_bounds__(PT_BLOCK) void k_first_logic(PathState ps, RenderCo
 }
 
 // ============================================================================================
-// compact + generate + shade: stable scatter into the camera / material queues and pixel tickets (logic.js:155-219),
-// then the slots' next rays by the same workgroup -- the camera ray of a slot that starts a sample (camera.js:60-118) or
-// the bounce ray of a slot that continues (material.js:75-120); both only touch that slot's own state, so neither
-// waits for a queue.  Workgroup 0 also closes the step's books in the StepHeader.
+// compact + shade (the kernel keeps the name it had when it also made the camera rays): stable scatter into the camera /
+// material queues and pixel tickets (logic.js:155-219), then the bounce ray of every slot that continues
+// (material.js:75-120) by the same workgroup.  Workgroup 0 also closes the step's books in the StepHeader.
 // No scan and no counting launch: the extend kernel's logic tail leaves one count record per 1024 slots (64-bit atomics,
 // two buffers alternating between steps; this launch clears the one the coming extend launch fills); a workgroup here adds up the records in
 // front of its 1024-slot group (<= 4 16-B loads per thread, L2 resident) and, when it is one of four per group,
@@ -73,7 +73,6 @@ __global__ __launch_bounds__(PT_BLOCK) void k_compact_generate_shade(PathState p
     static_assert(PER * PL * PT_BLOCK == PT_STEP_BLOCK, "a count record is a whole number of workgroups");
     __shared__ int4 s_cnt[PL][NW], s_front[NW], s_all[NW];
     __shared__ unsigned short s_todo[PL * PT_BLOCK];
-    __shared__ int s_px[PL * PT_BLOCK];
     const int b = blockIdx.x, base = b * PL * PT_BLOCK, group = b / PER, sub = b % PER, wave = threadIdx.x >> 6, lane = lane_id();
     unsigned code[PL]; unsigned long long b_cam[PL], b_mat[PL], b_tix[PL];
 #pragma unroll
@@ -130,35 +129,32 @@ __global__ __launch_bounds__(PT_BLOCK) void k_compact_generate_shade(PathState p
         loc[p] = tot;
         for (int w = 0; w < NW; w++) { int4 c = s_cnt[p][w]; if (w < wave) loc[p] = add4(loc[p], c); tot = add4(tot, c); }
     }
-    // Camera slots, then material slots, of the whole record are handed to the workgroup's threads in turn: whole waves
-    // run one body, and when the pool drains at the end of a render (a few live slots per record, tools/step_profile.py)
-    // one wave does the work.  A new pixel index travels with its slot through LDS.
+    // The material slots of the workgroup's planes are handed to its threads in turn through LDS: whole waves run the
+    // material sample, and when the pool drains at the end of a render (a few live slots per record,
+    // tools/step_profile.py) one wave does the work.  Camera slots only get their queue entry and, where due, their
+    // pixel ticket here: the camera ray itself is made by the extend kernel, which traces it at once.
 #pragma unroll
     for (int p = 0; p < PL; p++) {
         const int i = base + p * PT_BLOCK + (int)threadIdx.x, j = p * PT_BLOCK + (int)threadIdx.x;
         const int r_cam = rank_below(b_cam[p]), r_mat = rank_below(b_mat[p]);
-        if (code[p] & 1u) { cam_q[off.x + loc[p].x + r_cam] = i; s_todo[loc[p].x + r_cam] = (unsigned short)j; }
-        if (code[p] & 2u) { mat_q[off.y + loc[p].y + r_mat] = i; s_todo[tot.x + loc[p].y + r_mat] = (unsigned short)j; }
-        int px = -1;                                                                    // -1: the slot keeps its pixel
+        if (code[p] & 1u) cam_q[off.x + loc[p].x + r_cam] = i;
+        if (code[p] & 2u) { mat_q[off.y + loc[p].y + r_mat] = i; s_todo[loc[p].y + r_mat] = (unsigned short)j; }
         if (code[p] & 4u) {
             int64_t ticket = ticket_base + off.z + loc[p].z + rank_below(b_tix[p]);
             if (ticket >= rc.ticket_limit) ps.state[i] |= PT_ST_RETIRED;                // logic.js:177-179
             else {                                                                      // logic.js:181-182
-                px = (int32_t)(ticket % ((int64_t)rc.width * rc.height));
-                ps.pixel_index[i] = px;
+                ps.pixel_index[i] = (int32_t)(ticket % ((int64_t)rc.width * rc.height));
                 ps.state[i] &= ~(7u << 2);                                              // samples_in_pixel = 0
             }
         }
-        s_px[j] = px;
     }
     __syncthreads();
     auto body = [&](int t) {
-        const int j = s_todo[t], slot = base + j;
-        if (t < tot.x) generate_one(ps, rc, slot, s_px[j]);
-        else { int2 h = ps.hit[slot]; shade_one(ps, sc, slot, h.x, h.y); }
+        const int slot = base + s_todo[t];
+        int2 h = ps.hit[slot]; shade_one(ps, sc, slot, h.x, h.y);
     };
-    if (PL == 1) { if ((int)threadIdx.x < tot.x + tot.y) body((int)threadIdx.x); }      // no loop: 76 registers, 6 waves per SIMD
-    else for (int t = threadIdx.x; t < tot.x + tot.y; t += PT_BLOCK) body(t);
+    if (PL == 1) { if ((int)threadIdx.x < tot.y) body((int)threadIdx.x); }                  // no loop: fewer registers, 6 waves per SIMD
+    else for (int t = threadIdx.x; t < tot.y; t += PT_BLOCK) body(t);
 }
 
 // Adds the unfinished tickets' partial sums to the image (and clears them) so that a host looking at the image in

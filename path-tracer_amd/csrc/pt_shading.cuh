@@ -21,9 +21,10 @@ __device__ __forceinline__ P3 mk3(f3 v) { return mk3(v.x, v.y, v.z); }
 // ============================================================================================
 // generate (camera.js:60-118)
 // ============================================================================================
-// px_new: the pixel index the slot has just been given by this launch, or -1 when it keeps its pixel
-__device__ __forceinline__ void generate_one(const PathState& ps, const RenderConst& rc, int path, int px_new) {
-    int px = px_new >= 0 ? px_new : ps.pixel_index[path];
+// Runs in the extend kernel, for the entries of the camera queue (the ray goes straight into the traversal; the slot's
+// origin and direction are still stored, the material sample of the next step reads them).
+__device__ __forceinline__ void generate_one(const PathState& ps, const RenderConst& rc, int path, f3& ray_o, f3& ray_d) {
+    int px = ps.pixel_index[path];
     float seed = ps.random_seed[path];
     float2 r2 = rand2(seed);
     ps.random_seed[path] = seed + 2.0f;
@@ -40,6 +41,7 @@ __device__ __forceinline__ void generate_one(const PathState& ps, const RenderCo
     f3 d = (right * w.x + fwd * w.y) + up * w.z;
     ps.path_o[path] = mk3(pos);
     ps.path_d[path] = mk3(d);
+    ray_o = pos; ray_d = d;
 }
 
 // camera.js:96-111, the part that does not depend on the pixel
