@@ -144,7 +144,7 @@ def main():
         if args.png:
             disp = pta.init_display({"device": dev, "canvas": args.png, "image": {"buffer": image.data_ptr(), "width": w, "height": h}})
             disp.draw()
-        # one extend launch in eight is bracketed by HIP events (pt_render_run); mean over those, scaled to all launches
+        # one extend launch in sixteen is bracketed by HIP events (pt_render_run); mean over those, scaled to all launches
         all_launches = int(launches_per_render) * args.steps
         avg_s = extend_ms / 1e3 / max(launches, 1)
         ext_s = avg_s * all_launches

@@ -141,7 +141,7 @@ typedef struct {
     int64_t total_rays;         /* sum of stage-3 queue sizes */
     int64_t total_samples;      /* finished camera samples (= sum of image .w) */
     int64_t stack_overflows;    /* rays that hit the traversal guards (0 on sane scenes) */
-    double  extend_ms;          /* sum of the durations (HIP events) of the timed extend launches: one launch in eight */
+    double  extend_ms;          /* sum of the durations (HIP events) of the timed extend launches: one launch in sixteen */
     int64_t extend_launches;    /* how many launches were timed */
     int64_t traversal_bytes;    /* algorithmic bytes if counted, else 0 */
 } pt_run_stats;

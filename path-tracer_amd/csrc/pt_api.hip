@@ -546,9 +546,9 @@ int pt_render_step(pt_ctx* c, pt_step_stats* stats) {
 // batch b, so the GPU never idles for the read-back (a render ends with up to 2*POLL - 1 empty steps instead).  With
 // several contexts (pt_create_sharing_scene) the batches are issued in turn on the contexts' own streams, and one context's
 // count / compaction launches run in the tail of another's extend launch.
-// PT_RUN_TIME_EXTEND: one extend launch per batch is bracketed by events, at a position that rotates through the batch.
-// (Events around every launch were measured to cost 5.5 % of the render: each record is a barrier packet between two
-// kernels of a 120 us step.)
+// PT_RUN_TIME_EXTEND: one extend launch in every second batch (one in sixteen) is bracketed by events, at a position that
+// rotates through the batch.  (Events around every launch were measured to cost 5.5 % of the render, around one in eight
+// still 2 % with three pools: each record is a barrier packet between two kernels of a step.)
 namespace {
 struct RunState { pt_ctx* c; double extend_ms = 0.0; int64_t launches = 0, issued = 0, last = 0; bool had_timed[2] = {false, false}, more = false, done = false; };
 const int POLL = 8;   // steps between looks at the queue sizes (the reference never looks: main.js:61-72)
@@ -556,7 +556,7 @@ int run_issue(RunState& rs, int64_t batch, int64_t max_steps, bool timed, int co
     pt_ctx* c = rs.c;
     int p = (int)(batch & 1); rs.had_timed[p] = false;
     for (int k = 0; k < POLL && rs.issued < max_steps; k++, rs.issued++) {
-        bool t = timed && k == (int)(batch % POLL);
+        bool t = timed && (batch & 1) == 0 && k == (int)((batch >> 1) % POLL);   // one launch in 2 * POLL
         if (t) rs.had_timed[p] = true;
         enqueue_step(c, count, t ? c->events[3 * p] : nullptr, t ? c->events[3 * p + 1] : nullptr);
     }
