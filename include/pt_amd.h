@@ -50,7 +50,8 @@ typedef struct {
 /* ---- context ---- */
 /* replaces: navigator.gpu.requestAdapter()/requestDevice() (main.js:3-4) + initScene(device) (scene.js:1) */
 int         pt_create(int device_id, pt_ctx** out);
-void        pt_destroy(pt_ctx* ctx);
+/* PT_ERR_STATE (and nothing is freed) while contexts made by pt_create_sharing_scene still borrow this one's scene. */
+int         pt_destroy(pt_ctx* ctx);
 const char* pt_last_error(const pt_ctx* ctx);
 /* Optional: run all work on a caller-owned hipStream_t (e.g. torch's current stream). NULL = own stream. */
 int         pt_set_stream(pt_ctx* ctx, void* hip_stream);
@@ -87,6 +88,10 @@ int pt_scene_get_stack_bound(pt_ctx* ctx, int32_t* bound);
  * counts4 = per-ray {n_inner, n_leaf, n_enter, n_leave} visit counts. */
 int pt_trace_rays(pt_ctx* ctx, const float* o3, const float* d3, int64_t n,
                   int32_t* hit_obj, int32_t* hit_tri, float* hit_dist, int32_t* counts4);
+/* How many rays of the last pt_trace_rays call on this context were stopped by the traversal guards (a push onto a full
+ * 64-entry stack or more than 2^20 loop trips: the WGSL runtime's array clamp has no other counterpart); their hits are
+ * the ones found up to that point.  0 on every sane scene; parity tests assert it. */
+int pt_trace_last_guard_hits(pt_ctx* ctx, int64_t* out);
 
 /* ---- render (scripts/render) ---- */
 typedef struct {
@@ -154,7 +159,8 @@ int pt_render_run(pt_ctx* ctx, int64_t max_steps, int flags, pt_run_stats* out);
  * pt_create_sharing_scene: a second context on src's device that borrows src's built scene (no copy); it has its own
  * stream and its own render state (pt_render_init with its own slot_base / ticket range, like one GPU of a multi-GPU
  * render; give every context the same image_dev to accumulate one image).  It cannot upload meshes, build a scene or
- * change the traversal mode; destroy it before src, and rebuild nothing in src while it lives.
+ * change the traversal mode.  While it lives src keeps count of it: pt_scene_build, pt_set_traversal_mode and pt_destroy on
+ * src return PT_ERR_STATE, and so does pt_render_init on src while a borrower still accumulates into src's own image.
  * pt_render_run_many: pt_render_run over n such contexts at once from one host thread -- their batches of steps are
  * issued in turn on their own streams, so that one pool's compaction launches run in the tail of another's extend
  * launch.  out: n entries (or NULL).  Every pool is bit-identical to the oracle run with the same share; overlapping
@@ -166,6 +172,7 @@ int pt_render_run_many(pt_ctx** ctxs, int n, int64_t max_steps, int flags, pt_ru
  * rgba: W*H*4 floats (rgb = sum of radiance, a = finished samples; logic.js:146-149). */
 int pt_image_read(pt_ctx* ctx, float* rgba, int64_t n_floats);
 int pt_image_dev_ptr(pt_ctx* ctx, void** dev_ptr);
+int pt_image_size(pt_ctx* ctx, int32_t* width, int32_t* height);   /* params.image of the current render */
 /* Parity read-back of one PathState member (path-tracer.js:131-160) by name; vec3f/vec4f members
  * come back as 4 floats per slot.  "pixel_counter" returns one int64. */
 int pt_path_state_read(pt_ctx* ctx, const char* field, void* out, size_t bytes);

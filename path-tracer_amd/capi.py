@@ -54,7 +54,7 @@ class PtRenderExt(C.Structure):
 # name -> (restype, argtypes); every symbol include/pt_amd.h declares
 SIGNATURES = {
     "pt_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
-    "pt_destroy": (None, [C.c_void_p]),
+    "pt_destroy": (C.c_int, [C.c_void_p]),
     "pt_last_error": (C.c_char_p, [C.c_void_p]),
     "pt_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pt_sync": (C.c_int, [C.c_void_p]),
@@ -69,6 +69,8 @@ SIGNATURES = {
     "pt_get_mesh_perm": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
     "pt_scene_get_stack_bound": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "pt_trace_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pt_trace_last_guard_hits": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "pt_image_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "pt_render_init": (C.c_int, [C.c_void_p, C.POINTER(PtRenderParams)]),
     "pt_render_reset": (C.c_int, [C.c_void_p]),
     "pt_render_set_extensions": (C.c_int, [C.c_void_p, C.POINTER(PtRenderExt)]),

@@ -33,6 +33,9 @@ struct pt_ctx {
     std::vector<Mesh> meshes;
     // scene
     bool scene_borrowed = false;   // pt_create_sharing_scene: the scene buffers below belong to another context
+    pt_ctx* lender = nullptr;      // ... namely this one, which lists us in its `borrowers` until we are destroyed
+    std::vector<pt_ctx*> borrowers;
+    int64_t last_guard_hits = 0;   // pt_trace_rays: rays stopped by the traversal guards in the last call
     bool scene_built = false; int64_t n_tris = 0; int n_objects = 0; int n_meshes_used = 0; int32_t stack_bound = INT32_MAX;
     float4 *d_blas_nodes = nullptr, *d_blas_tris = nullptr, *d_tlas_nodes = nullptr, *d_objects = nullptr;
     float4* d_tri_records = nullptr;                    // SceneView::tris (edges + normal per packed triangle); d_blas_tris stays the reference's buffer
@@ -266,17 +269,21 @@ int pt_create_sharing_scene(pt_ctx* src, pt_ctx** out) {
     c->n_tris = src->n_tris; c->n_objects = src->n_objects; c->n_meshes_used = src->n_meshes_used; c->stack_bound = src->stack_bound;
     c->d_blas_nodes = src->d_blas_nodes; c->d_blas_tris = src->d_blas_tris; c->d_tlas_nodes = src->d_tlas_nodes; c->d_objects = src->d_objects;
     c->d_tlas_perm = src->d_tlas_perm; c->d_tri_records = src->d_tri_records; c->d_wide = src->d_wide; c->traversal_mode = src->traversal_mode;
+    c->lender = src; src->borrowers.push_back(c);
     return PT_OK;
 }
 
-void pt_destroy(pt_ctx* c) {
-    if (!c) return;
+int pt_destroy(pt_ctx* c) {
+    if (!c) return PT_OK;
+    if (!c->borrowers.empty()) return fail(c, PT_ERR_STATE, "pt_destroy: " + std::to_string(c->borrowers.size()) + " context(s) still borrow this context's scene; destroy them first");
+    if (c->lender) { auto& b = c->lender->borrowers; b.erase(std::remove(b.begin(), b.end(), c), b.end()); }
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     free_render(c); free_scene(c);
     for (Mesh& m : c->meshes) { dfree(m.d_tris_in); dfree(m.d_nodes); dfree(m.d_tris_sorted); dfree(m.d_perm); }
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
+    return PT_OK;
 }
 
 const char* pt_last_error(const pt_ctx* c) { return c ? c->err.c_str() : g_err.c_str(); }
@@ -317,6 +324,7 @@ int pt_scene_build(pt_ctx* c, const pt_instance* inst, int n_inst) {
     if (!c || !inst) return fail(c, PT_ERR_ARG, "pt_scene_build: null argument");
     if (c->scene_borrowed) return fail(c, PT_ERR_STATE, "pt_scene_build: this context borrows another context's scene");
     if (n_inst < 1) return fail(c, PT_ERR_ARG, "pt_scene_build: the scene needs at least one instance");
+    if (!c->borrowers.empty()) return fail(c, PT_ERR_STATE, "pt_scene_build: other contexts still borrow this context's scene (pt_create_sharing_scene); destroy them first");
     HIPOK(c, hipSetDevice(c->device));
     for (int i = 0; i < n_inst; i++)
         if (inst[i].mesh < 0 || inst[i].mesh >= (int)c->meshes.size())   // scene.js:524-526
@@ -375,6 +383,7 @@ int pt_scene_build(pt_ctx* c, const pt_instance* inst, int n_inst) {
 int pt_set_traversal_mode(pt_ctx* c, int mode) {
     if (!c || (mode != PT_TRAVERSAL_REFERENCE && mode != PT_TRAVERSAL_WIDE)) return fail(c, PT_ERR_ARG, "pt_set_traversal_mode: unknown mode");
     if (c->scene_borrowed) return fail(c, PT_ERR_STATE, "pt_set_traversal_mode: this context borrows another context's scene (set the mode there first)");
+    if (!c->borrowers.empty() && mode != c->traversal_mode) return fail(c, PT_ERR_STATE, "pt_set_traversal_mode: other contexts still borrow this context's scene; destroy them first");
     HIPOK(c, hipSetDevice(c->device));
     HIPOK(c, hipStreamSynchronize(c->stream));
     c->traversal_mode = mode;
@@ -431,6 +440,7 @@ int pt_trace_rays(pt_ctx* c, const float* o3, const float* d3, int64_t n, int32_
         return rc;
     std::vector<float> stage((size_t)cap * 4);
     SceneView sv = scene_view(c);
+    c->last_guard_hits = 0;
     for (int64_t base = 0; base < n; base += CH) {
         int64_t m = std::min(CH, n - base);
         for (int pass = 0; pass < 2; pass++) {
@@ -439,7 +449,7 @@ int pt_trace_rays(pt_ctx* c, const float* o3, const float* d3, int64_t n, int32_
             HIPOK(c, hipMemcpyAsync(pass ? d_d : d_o, stage.data(), (size_t)m * 16, hipMemcpyHostToDevice, c->stream));
             HIPOK(c, hipStreamSynchronize(c->stream));
         }
-        ptk_extend_direct(sv, d_o, d_d, (int)m, d_ho, d_ht, d_hd, counts4 ? d_cnt : nullptr, d_spill, d_hdr, c->stream);
+        ptk_extend_direct(sv, (const float*)d_o, (const float*)d_d, 4, (int)m, d_ho, d_ht, d_hd, counts4 ? d_cnt : nullptr, d_spill, d_hdr, c->stream);
         HIPOK(c, hipGetLastError());
         if (hit_obj) HIPOK(c, hipMemcpyAsync(hit_obj + base, d_ho, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
         if (hit_tri) HIPOK(c, hipMemcpyAsync(hit_tri + base, d_ht, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
@@ -447,6 +457,15 @@ int pt_trace_rays(pt_ctx* c, const float* o3, const float* d3, int64_t n, int32_
         if (counts4) HIPOK(c, hipMemcpyAsync(counts4 + 4 * base, d_cnt, (size_t)m * 16, hipMemcpyDeviceToHost, c->stream));
         HIPOK(c, hipStreamSynchronize(c->stream));
     }
+    unsigned long long guard_hits = 0;   // the kernel adds every ray its stack / iteration guards stopped to StepHeader::overflow
+    if ((rc = read_back(c, &guard_hits, &d_hdr->overflow, sizeof guard_hits))) return rc;
+    c->last_guard_hits = (int64_t)guard_hits;
+    return PT_OK;
+}
+
+int pt_trace_last_guard_hits(pt_ctx* c, int64_t* out) {
+    if (!c || !out) return fail(c, PT_ERR_ARG, "pt_trace_last_guard_hits: null argument");
+    *out = c->last_guard_hits;
     return PT_OK;
 }
 
@@ -458,6 +477,9 @@ int pt_render_init(pt_ctx* c, const pt_render_params* p) {
         return fail(c, PT_ERR_ARG, "pt_render_init: bad image size or spp");
     int64_t np = p->num_paths > 0 ? p->num_paths : 1000000;   // path-tracer.js:4
     if (np > (1ll << 28)) return fail(c, PT_ERR_ARG, "pt_render_init: num_paths too large");
+    for (pt_ctx* b : c->borrowers)    // a pool context that adds into this context's own image would be left with a dangling pointer
+        if (c->render_ready && c->own_image && b->render_ready && b->d_image == c->d_image)
+            return fail(c, PT_ERR_STATE, "pt_render_init: a context made by pt_create_sharing_scene still accumulates into this context's image; destroy it (or give it another image) first");
     HIPOK(c, hipSetDevice(c->device));
     HIPOK(c, hipStreamSynchronize(c->stream));
     free_render(c);
@@ -653,6 +675,13 @@ int pt_image_dev_ptr(pt_ctx* c, void** dev_ptr) {
     if (!c || !dev_ptr) return fail(c, PT_ERR_ARG, "pt_image_dev_ptr: null argument");
     if (!c->render_ready) return fail(c, PT_ERR_STATE, "pt_image_dev_ptr: pt_render_init has not been called");
     *dev_ptr = c->d_image;
+    return PT_OK;
+}
+
+int pt_image_size(pt_ctx* c, int32_t* width, int32_t* height) {
+    if (!c || !width || !height) return fail(c, PT_ERR_ARG, "pt_image_size: null argument");
+    if (!c->render_ready) return fail(c, PT_ERR_STATE, "pt_image_size: pt_render_init has not been called");
+    *width = c->rc.width; *height = c->rc.height;
     return PT_OK;
 }
 

@@ -129,9 +129,11 @@ void ptk_extend_queue(const PathState& ps, const RenderConst& rc, const SceneVie
 int64_t ptk_extend_waves(int num_paths, int variant);   // waves the launch of that variant holds (wave_log entries)
 int ptk_extend_num_variants();
 const char* ptk_extend_variant_name(int v);
-// Extend over n caller rays (o4/d4: float4 per ray).  counts4 (int4 per ray) may be null.
-void ptk_extend_direct(const SceneView& sc, const float4* o4, const float4* d4, int n, int32_t* hit_obj,
+// Extend over n caller rays (o / d: `stride` floats per ray, 4 = float4 records, 3 = packed).  Any output may be null.
+// spill: ptk_direct_spill_ints(n) ints.
+void ptk_extend_direct(const SceneView& sc, const float* o, const float* d, int stride, int n, int32_t* hit_obj,
                        int32_t* hit_tri, float* hit_dist, int4* counts4, int32_t* spill, StepHeader* hdr, hipStream_t s);
+size_t ptk_direct_spill_ints(int64_t n_rays);
 void ptk_camera_frame(const RenderConst& rc, CameraFrame* out_dev, hipStream_t s);   // one thread; the host copies the result into rc.frame
 void ptk_flush_tickets(const PathState& ps, int num_paths, float* image, hipStream_t s);
 void ptk_tonemap(const float4* image, int64_t n_pixels, uint32_t* rgba8, hipStream_t s);

@@ -300,8 +300,9 @@ __global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView 
 // --------------------------------------------------------------------------------------------
 // Test hook: caller-supplied rays, always counting (pt_trace_rays)
 // --------------------------------------------------------------------------------------------
-template <bool WIDE>
-__global__ __launch_bounds__(PT_BLOCK) void k_extend_direct(SceneView sc, const float4* __restrict__ o4, const float4* __restrict__ d4, int n,
+// STRIDE: floats per ray in o / d (4: the staged float4 arrays of pt_trace_rays; 3: the caller's packed arrays, pt_trace_rays_noalloc).
+template <bool WIDE, int STRIDE>
+__global__ __launch_bounds__(PT_BLOCK) void k_extend_direct(SceneView sc, const float* __restrict__ o, const float* __restrict__ d, int n,
                                                             int32_t* __restrict__ hit_obj, int32_t* __restrict__ hit_tri,
                                                             float* __restrict__ hit_dist, int4* __restrict__ counts4, int32_t* spill,
                                                             int64_t spill_stride, StepHeader* hdr) {
@@ -309,11 +310,14 @@ __global__ __launch_bounds__(PT_BLOCK) void k_extend_direct(SceneView sc, const 
     int q = blockIdx.x * PT_BLOCK + threadIdx.x;
     Ray r; ray_init(r, F3(0, 0, 1), F3(0, 0, 1));
     if (q < n) {
-        ray_init(r, F3(o4[q]), F3(d4[q]));
+        if (STRIDE == 4) ray_init(r, F3(((const float4*)o)[q]), F3(((const float4*)d)[q]));
+        else ray_init(r, F3(o[3 * (int64_t)q], o[3 * (int64_t)q + 1], o[3 * (int64_t)q + 2]), F3(d[3 * (int64_t)q], d[3 * (int64_t)q + 1], d[3 * (int64_t)q + 2]));
         Stack<PT_LDS_STACK, PT_BLOCK> stk{s_stack + threadIdx.x, spill + q, spill_stride};
         while (trav_step<true, Stack<PT_LDS_STACK, PT_BLOCK>, WIDE>(sc, r, stk)) {}
         trav_finish<true>(sc, r);
-        hit_obj[q] = r.hit_obj; hit_tri[q] = r.hit_tri; hit_dist[q] = r.hit_dist;
+        if (hit_obj) hit_obj[q] = r.hit_obj;
+        if (hit_tri) hit_tri[q] = r.hit_tri;
+        if (hit_dist) hit_dist[q] = r.hit_dist;
         if (counts4) counts4[q] = make_int4(r.n_inner, r.n_leaf, r.n_enter, r.n_leave);
     }
     publish<false>(r.overflow, 0, 0, 0, 0, hdr);
@@ -376,10 +380,13 @@ int64_t ptk_extend_waves(int num_paths, int variant) {
     int block = (variant == 0 || variant == 3) ? 256 : 64;   // variant 3 falls back to 64 when the scene does not fit: an upper bound then
     return (int64_t)((num_paths + block - 1) / block) * (block / 64);
 }
-void ptk_extend_direct(const SceneView& sc, const float4* o4, const float4* d4, int n, int32_t* hit_obj, int32_t* hit_tri,
+size_t ptk_direct_spill_ints(int64_t n_rays) { return (size_t)pad_to(n_rays, 256) * (PT_STACK_SIZE - PT_LDS_STACK); }
+void ptk_extend_direct(const SceneView& sc, const float* o, const float* d, int stride, int n, int32_t* hit_obj, int32_t* hit_tri,
                        float* hit_dist, int4* counts4, int32_t* spill, StepHeader* hdr, hipStream_t s) {
-    if (sc.wide) hipLaunchKernelGGL(k_extend_direct<true>, dim3((unsigned)((n + PT_BLOCK - 1) / PT_BLOCK)), dim3(PT_BLOCK), 0, s, sc, o4, d4, n, hit_obj,
-                       hit_tri, hit_dist, counts4, spill, pad_to(n, 256), hdr);
-    else hipLaunchKernelGGL(k_extend_direct<false>, dim3((unsigned)((n + PT_BLOCK - 1) / PT_BLOCK)), dim3(PT_BLOCK), 0, s, sc, o4, d4, n, hit_obj,
-                       hit_tri, hit_dist, counts4, spill, pad_to(n, 256), hdr);
+    const dim3 grid((unsigned)((n + PT_BLOCK - 1) / PT_BLOCK)), block(PT_BLOCK);
+    const int64_t spill_stride = pad_to(n, 256);
+#define PT_DIRECT(W, S) hipLaunchKernelGGL((k_extend_direct<W, S>), grid, block, 0, s, sc, o, d, n, hit_obj, hit_tri, hit_dist, counts4, spill, spill_stride, hdr)
+    if (sc.wide) { if (stride == 4) PT_DIRECT(true, 4); else PT_DIRECT(true, 3); }
+    else         { if (stride == 4) PT_DIRECT(false, 4); else PT_DIRECT(false, 3); }
+#undef PT_DIRECT
 }

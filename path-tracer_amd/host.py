@@ -179,7 +179,9 @@ class Device:
 
     def destroy(self):
         if self.ctx:
-            self.lib.pt_destroy(self.ctx)
+            rc = self.lib.pt_destroy(self.ctx)      # refused (PT_ERR_STATE) while pool contexts still borrow this one's scene
+            if rc < 0:
+                raise capi.PtError(f"pt_destroy failed ({rc}): {self.lib.pt_last_error(self.ctx).decode()}")
             self.ctx = None
 
     def __del__(self):
@@ -275,6 +277,9 @@ class Scene:
         self.device.call("pt_trace_rays", o.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p), n,
                          ho.ctypes.data_as(C.c_void_p), ht.ctypes.data_as(C.c_void_p), hd.ctypes.data_as(C.c_void_p),
                          cn.ctypes.data_as(C.c_void_p) if counts else None)
+        g = C.c_int64()
+        self.device.call("pt_trace_last_guard_hits", C.byref(g))
+        self.last_guard_hits = g.value      # rays stopped by the stack / iteration guards (0 on every sane scene)
         return (ho, ht, hd, cn) if counts else (ho, ht, hd)
 
 

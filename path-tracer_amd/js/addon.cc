@@ -29,6 +29,7 @@ static bool get_args(napi_env env, napi_callback_info info, size_t want, napi_va
 static pt_ctx* ctx_of(napi_env env, napi_value v) {
     void* p = nullptr;
     if (napi_get_value_external(env, v, &p) != napi_ok || !p) { napi_throw_type_error(env, nullptr, "expected a pt context"); return nullptr; }
+    if (!*(pt_ctx**)p) { napi_throw_error(env, nullptr, "context destroyed"); return nullptr; }
     return *(pt_ctx**)p;
 }
 // typed array -> pointer + byte length (null for JS null/undefined)
@@ -89,7 +90,12 @@ static napi_value CreateSharingScene(napi_env env, napi_callback_info info) {
 static napi_value Destroy(napi_env env, napi_callback_info info) {
     napi_value a[1]; if (!get_args(env, info, 1, a)) return nullptr;
     void* p = nullptr; napi_get_value_external(env, a[0], &p);
-    if (p && *(pt_ctx**)p) { pt_destroy(*(pt_ctx**)p); *(pt_ctx**)p = nullptr; }
+    if (p && *(pt_ctx**)p) {
+        pt_ctx* c = *(pt_ctx**)p;
+        int rc = pt_destroy(c);                    // refused while pool contexts still borrow this one's scene
+        if (rc < 0) return throw_pt(env, c, "pt_destroy", rc);
+        *(pt_ctx**)p = nullptr;
+    }
     return nullptr;
 }
 // meshUpload(ctx, Float32Array tris12, Float32Array bounds6) -> handle     [pt_mesh_upload]
@@ -253,6 +259,7 @@ static napi_value ImageRead(napi_env env, napi_callback_info info) {
     napi_value a[2]; if (!get_args(env, info, 2, a)) return nullptr;
     pt_ctx* c = ctx_of(env, a[0]); if (!c) return nullptr;
     void* d; size_t nb; if (!ta(env, a[1], &d, &nb)) return nullptr;
+    if (!d) { napi_throw_type_error(env, nullptr, "imageRead: expected a Float32Array"); return nullptr; }
     int rc = pt_image_read(c, (float*)d, (int64_t)(nb / 4));
     if (rc < 0) return throw_pt(env, c, "pt_image_read", rc);
     return nullptr;
@@ -262,6 +269,9 @@ static napi_value Tonemap(napi_env env, napi_callback_info info) {
     napi_value a[2]; if (!get_args(env, info, 2, a)) return nullptr;
     pt_ctx* c = ctx_of(env, a[0]); if (!c) return nullptr;
     void* d; size_t nb; if (!ta(env, a[1], &d, &nb)) return nullptr;
+    int32_t w = 0, h = 0; int rs = pt_image_size(c, &w, &h);
+    if (rs < 0) return throw_pt(env, c, "pt_image_size", rs);
+    if (!d || nb != (size_t)w * (size_t)h * 4) { napi_throw_range_error(env, nullptr, "tonemap: the Uint8Array must hold width * height * 4 bytes of the current render"); return nullptr; }
     int rc = pt_tonemap_rgba8(c, nullptr, 0, 0, (uint8_t*)d);
     if (rc < 0) return throw_pt(env, c, "pt_tonemap_rgba8", rc);
     return nullptr;

@@ -64,6 +64,7 @@ async function main() {
     const report = { width, height, samples, steps, rays, frames: frames + 1, buildMs: t1 - t0, renderMs: t2 - t1, sampleCount: wsum, radianceSum: rsum,
                      firstPixel: Array.from(rgba.slice(0, 4)), info: scene.kernels.getSceneBindGroupInfo() }
     console.log(arg("json", false) ? JSON.stringify(report) : report)
+    tracer.destroy()                 // pool contexts borrow the device's scene: they go first
     device.destroy()
 }
 

@@ -164,7 +164,7 @@ function initPathTracer(params) {
         addon().imageRead(device.ctx, out)
         return out
     }
-    return { step, getImageBuffer, run, readImage, reset: () => addon().renderReset(device.ctx) }
+    return { step, getImageBuffer, run, readImage, reset: () => addon().renderReset(device.ctx), destroy() {} }
 }
 
 // settings.pools = K > 1 (no reference counterpart): K path pools of settings.numPaths slots on one GPU -- contexts that
@@ -196,7 +196,8 @@ function initPooledPathTracer(params) {
         const sum = f => r.reduce((a, x) => a + x[f], 0)
         return { camera: sum("camera"), material: sum("material"), rays: sum("rays"), step: r[0].step, pools: r }
     }
-    return { step, run, readImage, pools, getImageBuffer: pools[0].getImageBuffer, reset: () => pools.forEach(p => p.reset()) }
+    function destroy() { for (let k = K - 1; k > 0; k--) addon().destroy(pools[k].device.ctx) }   // the borrowers; pool 0 is the caller's device
+    return { step, run, readImage, pools, destroy, getImageBuffer: pools[0].getImageBuffer, reset: () => pools.forEach(p => p.reset()) }
 }
 
 // ---- initDisplay (display.js): the canvas is a PNG (or raw RGBA8) ------------------------------------------------

@@ -83,7 +83,7 @@ def test_closest_hit_bit_exact(built, name):
     ro, rd = rays_for(desc, 200_000, 7)
     g_obj, g_tri, g_dist, g_cnt = s.trace_rays(ro, rd, counts=True)
     c_obj, c_tri, c_dist, c_cnt = o.trace_rays(ro, rd, counts=True)
-    assert o.last_overflow == 0
+    assert o.last_overflow == 0 and s.last_guard_hits == 0
     np.testing.assert_array_equal(g_obj, c_obj)
     np.testing.assert_array_equal(g_tri, c_tri)
     np.testing.assert_array_equal(g_dist.view(np.uint32), c_dist.view(np.uint32))
@@ -594,8 +594,15 @@ def test_pools_on_one_gpu(pta, orc, device, built):
     np.testing.assert_allclose(img2[..., :3], img[..., :3], rtol=2e-5, atol=1e-5)
     with pytest.raises(pta.capi.PtError, match="borrows"):
         pta.init_scene(pt.pools[1].device).register_mesh(pta.scenes.cornell_box()["meshes"][0])
+    # the owner keeps count of its borrowers: it cannot rebuild its scene, replace the image they add into, or go away
+    with pytest.raises(pta.capi.PtError, match="still borrow"):
+        s.build()
+    with pytest.raises(pta.capi.PtError, match="accumulates into"):
+        pta.init_path_tracer({"device": device, "scene": s, "image": {"width": 8, "height": 8}, "camera": desc["camera"], "settings": {"samples": 8, "numPaths": 64}})
+    assert device.lib.pt_destroy(device.ctx) == -3 and b"still borrow" in device.lib.pt_last_error(device.ctx)      # PT_ERR_STATE
     import ctypes as C
     twice = (C.c_void_p * 2)(pt.pools[1].device.ctx, pt.pools[1].device.ctx)
     assert device.lib.pt_render_run_many(twice, 2, 0, 0, None) == -1          # PT_ERR_ARG
     assert b"twice" in device.lib.pt_last_error(pt.pools[1].device.ctx)
     pt.destroy()
+    s.build()                                                                 # borrowers gone: allowed again
