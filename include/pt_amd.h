@@ -93,6 +93,21 @@ int pt_trace_rays(pt_ctx* ctx, const float* o3, const float* d3, int64_t n,
  * the ones found up to that point.  0 on every sane scene; parity tests assert it. */
 int pt_trace_last_guard_hits(pt_ctx* ctx, int64_t* out);
 
+/* pt_trace_rays for callers that cannot allocate -- NO counterpart in the reference (a WebGPU host cannot be in that position);
+ * it exists for code under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same kernel, same
+ * results as pt_trace_rays, but: every pointer is a DEVICE address on the ctx's GPU (o3_dev / d3_dev: n x 3 packed floats;
+ * outputs as in pt_trace_rays, any may be NULL; counts4_dev 16-byte aligned; guard_hits_dev: one uint64 = rays stopped by the
+ * traversal guards); the call allocates and frees nothing, waits for nothing, and returns once the work is on the ctx's
+ * stream (pt_sync or the caller's own stream ordering makes the outputs readable).  The traversal-stack spill and the guard
+ * counter live in a file-scope device array of the library (10.5 MB on every GPU that loads it, for the life of the process)
+ * sized for chunks of 65,536 rays; a call works through its rays chunk by chunk.  At most PT_TRACE_NOALLOC_MAX_RAYS rays per
+ * call: more is PT_ERR_ARG.  All contexts of one GPU share that array: calls that overlap on one GPU (two contexts, two
+ * streams, two threads) race on it -- issue them one after the other. */
+#define PT_TRACE_NOALLOC_MAX_RAYS 4194304
+int pt_trace_rays_noalloc(pt_ctx* ctx, const float* o3_dev, const float* d3_dev, int64_t n,
+                          int32_t* hit_obj_dev, int32_t* hit_tri_dev, float* hit_dist_dev, int32_t* counts4_dev,
+                          uint64_t* guard_hits_dev);
+
 /* ---- render (scripts/render) ---- */
 typedef struct {
     int32_t width, height;           /* params.image (path-tracer.js:57-58) */

@@ -39,6 +39,7 @@ class PtRunStats(C.Structure):
 
 
 PT_TRAVERSAL_REFERENCE, PT_TRAVERSAL_WIDE = 0, 1
+PT_TRACE_NOALLOC_MAX_RAYS = 4194304
 PT_MAT_LAMBERT, PT_MAT_EMITTER, PT_MAT_MIRROR, PT_MAX_EXT_MATERIALS = 0, 1, 2, 14
 
 
@@ -70,6 +71,7 @@ SIGNATURES = {
     "pt_scene_get_stack_bound": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "pt_trace_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pt_trace_last_guard_hits": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "pt_trace_rays_noalloc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pt_image_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "pt_render_init": (C.c_int, [C.c_void_p, C.POINTER(PtRenderParams)]),
     "pt_render_reset": (C.c_int, [C.c_void_p]),

@@ -7,15 +7,44 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
 static_assert(sizeof(pt_bvh_node) == 64 && sizeof(pt_triangle) == 48 && sizeof(pt_object) == 128, "record layouts");
 static_assert(sizeof(pt_instance) == 160, "pt_instance is 40 words (k_pack_objects)");
 
+// ---- scratch of pt_trace_rays_noalloc: device memory that belongs to the code object, so the entry point allocates nothing ----
+// [StepHeader (guard counter), padded to PT_NOALLOC_HDR_BYTES | traversal-stack spill of one chunk of PT_NOALLOC_CHUNK rays]
+// Every GPU that loads the library holds its own copy of this array (10.5 MB) until the process ends.  In host code the name
+// `scratch` is only a handle: the device address is asked for once per device (scratch_address, called by pt_create with that
+// device current) and everything below uses that pointer.
+#define PT_NOALLOC_CHUNK 65536
+#define PT_NOALLOC_HDR_BYTES 4096
+#define PT_NOALLOC_SCRATCH_BYTES (PT_NOALLOC_HDR_BYTES + (size_t)PT_NOALLOC_CHUNK * (PT_STACK_SIZE - PT_LDS_STACK) * 4)
+static_assert(sizeof(StepHeader) <= PT_NOALLOC_HDR_BYTES && PT_NOALLOC_CHUNK % 256 == 0, "scratch layout");
+static __device__ __align__(256) unsigned char scratch[PT_NOALLOC_SCRATCH_BYTES];
+
 namespace {
 
 thread_local std::string g_err;   // errors raised before a ctx exists
+
+constexpr int PT_MAX_DEVICES = 64;
+std::mutex g_scratch_mutex;
+void* g_scratch_ptr[PT_MAX_DEVICES];   // device address of `scratch` on each GPU, null until asked for
+
+// The current device must be `device`.
+hipError_t scratch_address(int device, void** out) {
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        g_scratch_ptr[device] = p;
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
 
 struct Mesh {
     int64_t n = 0; float bounds[6] = {0, 0, 0, 0, 0, 0};
@@ -36,6 +65,7 @@ struct pt_ctx {
     pt_ctx* lender = nullptr;      // ... namely this one, which lists us in its `borrowers` until we are destroyed
     std::vector<pt_ctx*> borrowers;
     int64_t last_guard_hits = 0;   // pt_trace_rays: rays stopped by the traversal guards in the last call
+    void* d_scratch = nullptr;     // this GPU's copy of the file-scope `scratch` array (pt_trace_rays_noalloc)
     bool scene_built = false; int64_t n_tris = 0; int n_objects = 0; int n_meshes_used = 0; int32_t stack_bound = INT32_MAX;
     float4 *d_blas_nodes = nullptr, *d_blas_tris = nullptr, *d_tlas_nodes = nullptr, *d_objects = nullptr;
     float4* d_tri_records = nullptr;                    // SceneView::tris (edges + normal per packed triangle); d_blas_tris stays the reference's buffer
@@ -246,11 +276,15 @@ int pt_create(int device_id, pt_ctx** out) {
     *out = nullptr;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(nullptr, PT_ERR_NOGPU, "pt_create: no HIP device visible");
-    if (device_id < 0 || device_id >= n) return fail(nullptr, PT_ERR_ARG, "pt_create: device_id out of range");
+    if (device_id < 0 || device_id >= n || device_id >= PT_MAX_DEVICES) return fail(nullptr, PT_ERR_ARG, "pt_create: device_id out of range");
     pt_ctx* c = new pt_ctx();
     c->device = device_id;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
         delete c; return fail(nullptr, PT_ERR_HIP, "pt_create: hipSetDevice/hipStreamCreate failed");
+    }
+    if (hipError_t e = scratch_address(device_id, &c->d_scratch); e != hipSuccess) {
+        (void)hipStreamDestroy(c->stream); delete c;
+        return fail(nullptr, PT_ERR_HIP, std::string("pt_create: hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
     }
     c->own_stream = true;
     c->extend_variant = 3;   // 8 waves/SIMD, class of the longest wave first, a tiny scene staged in LDS (tools/extend_ab.py)
@@ -460,6 +494,31 @@ int pt_trace_rays(pt_ctx* c, const float* o3, const float* d3, int64_t n, int32_
     unsigned long long guard_hits = 0;   // the kernel adds every ray its stack / iteration guards stopped to StepHeader::overflow
     if ((rc = read_back(c, &guard_hits, &d_hdr->overflow, sizeof guard_hits))) return rc;
     c->last_guard_hits = (int64_t)guard_hits;
+    return PT_OK;
+}
+
+// No hipMalloc / hipFree / allocating call below this line of the function: the spill and the guard counter live in `scratch`
+// (through c->d_scratch, this GPU's address of it), inputs and outputs are the caller's device memory.  Nothing is waited for.
+int pt_trace_rays_noalloc(pt_ctx* c, const float* o3_dev, const float* d3_dev, int64_t n, int32_t* hit_obj_dev, int32_t* hit_tri_dev,
+                          float* hit_dist_dev, int32_t* counts4_dev, uint64_t* guard_hits_dev) {
+    if (!c || !o3_dev || !d3_dev || n < 0) return fail(c, PT_ERR_ARG, "pt_trace_rays_noalloc: bad argument");
+    if (n > PT_TRACE_NOALLOC_MAX_RAYS)
+        return fail(c, PT_ERR_ARG, "pt_trace_rays_noalloc: " + std::to_string(n) + " rays, at most " + std::to_string(PT_TRACE_NOALLOC_MAX_RAYS) + " per call (split the batch, or use pt_trace_rays)");
+    if (((uintptr_t)counts4_dev & 15) != 0) return fail(c, PT_ERR_ARG, "pt_trace_rays_noalloc: counts4_dev must be 16-byte aligned");
+    if (!c->scene_built) return fail(c, PT_ERR_STATE, "scene has not been built yet");
+    HIPOK(c, hipSetDevice(c->device));
+    StepHeader* hdr = (StepHeader*)c->d_scratch;
+    int32_t* spill = (int32_t*)((unsigned char*)c->d_scratch + PT_NOALLOC_HDR_BYTES);
+    HIPOK(c, hipMemsetAsync(hdr, 0, sizeof(StepHeader), c->stream));    // the array keeps the last call's contents: the guard counter starts at 0
+    SceneView sv = scene_view(c);
+    for (int64_t base = 0; base < n; base += PT_NOALLOC_CHUNK) {       // chunks run one after the other on the stream and share the spill
+        int64_t m = std::min<int64_t>(PT_NOALLOC_CHUNK, n - base);
+        ptk_extend_direct(sv, o3_dev + 3 * base, d3_dev + 3 * base, 3, (int)m, hit_obj_dev ? hit_obj_dev + base : nullptr,
+                          hit_tri_dev ? hit_tri_dev + base : nullptr, hit_dist_dev ? hit_dist_dev + base : nullptr,
+                          counts4_dev ? (int4*)counts4_dev + base : nullptr, spill, hdr, c->stream);
+    }
+    HIPOK(c, hipGetLastError());
+    if (guard_hits_dev) HIPOK(c, hipMemcpyAsync(guard_hits_dev, &hdr->overflow, sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
     return PT_OK;
 }
 
