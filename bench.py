@@ -3,15 +3,18 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-Metric (BASELINE.json): Mrays/s at 1920x1080.  Workload at N=1: configs[1], the Cornell box at 1920x1080,
-64 spp, 3 path pools of 750,000 slots in flight (--pools, --paths; the reference has one pool of NUM_PATHS = 1,000,000).
-One "step" = one complete render of that frame: every wavefront iteration (compact+generate+shade -> extend+logic) until both
-stage-2 queues are empty, with the scene and all buffers already resident in HBM.  N > 1: one process per GPU (torchrun),
-each GPU renders the full 64 spp with its own RNG streams (slot_base = (rank * pools + pool) * NUM_PATHS) and its own ticket
-range, i.e. the node accumulates N*64 spp ("weak": per-GPU work fixed); the per-GPU accumulation buffers are
-combined by one RCCL sum-reduce to rank 0 inside the timed region of every step.
+Metric (BASELINE.json): Mrays/s (+ samples/s) at 1920x1080.  Workload at N=1: BASELINE configs[2], the 81,920-triangle displaced
+icosphere over the reference's floor at 1920x1080, 256 spp -- the largest single-GPU configuration the metric is quoted at
+(configs[1], the 34-triangle Cornell box, is rendered too and reported in `also`; --config picks any other).
+One "step" = one complete render of that frame: every wavefront iteration (compact+shade -> generate+extend+logic) until both
+stage-2 queues are empty, with the scene and all buffers already resident in HBM.  3 path pools of 750,000 slots are in flight
+per GPU (--pools, --paths); the reference's own shape, one pool of NUM_PATHS = 1,000,000, is timed as well (`reference_pool_shape`).
+N > 1: one process per GPU (torchrun), each GPU renders the full spp with its own RNG streams (slot_base = (rank * pools + pool)
+* NUM_PATHS) and its own ticket range, i.e. the node accumulates N*spp ("weak": per-GPU work fixed); the per-GPU accumulation
+buffers are combined by one RCCL sum-reduce to rank 0 inside the timed region of every step.
 
-Prints ONE JSON line on rank 0 with `roofline` (extend kernel, HBM bound) and `cpu_baseline` (oracle, N=1 only).
+Prints ONE JSON line on rank 0.  `roofline` describes the extend kernel from an EXCLUSIVE pass (one pool, so its launches do not
+overlap anything) that runs after the timed region; `cpu_baseline` is the oracle on the host cores (N=1 only).
 """
 import argparse
 import importlib
@@ -28,13 +31,37 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 
 CONFIGS = {
-    # name: (scene factory name, kwargs, width, height, spp)
-    "cornell": ("cornell_box", {}, 1920, 1080, 64),          # BASELINE configs[1]  (the metric's configuration)
-    "floor": ("floor_scene", {}, 512, 512, 16),              # BASELINE configs[0]
-    "sphere": ("bunny_scale_scene", {}, 1920, 1080, 256),    # BASELINE configs[2]
-    "grid": ("grid_scene", {}, 3840, 2160, 32),              # BASELINE configs[3]: 32 spp per GPU
-    "instanced": ("instanced_scene", {}, 3840, 2160, 32),    # BASELINE configs[4]
+    # name: (scene factory name, kwargs, width, height, spp, BASELINE.json configs index)
+    "sphere": ("bunny_scale_scene", {}, 1920, 1080, 256, 2),    # the metric's configuration at N=1 (default)
+    "cornell": ("cornell_box", {}, 1920, 1080, 64, 1),
+    "floor": ("floor_scene", {}, 512, 512, 16, 0),
+    "grid": ("grid_scene", {}, 3840, 2160, 32, 3),              # 32 spp per GPU
+    "instanced": ("instanced_scene", {}, 3840, 2160, 32, 4),
 }
+
+
+def build_scene(pta, dev, name):
+    factory, kwargs, w, h, spp, idx = CONFIGS[name]
+    desc = getattr(pta.scenes, factory)(**kwargs)
+    t0 = time.time()
+    scene = pta.scenes.populate(pta.init_scene(dev), desc)
+    scene.build()
+    return desc, scene, time.time() - t0
+
+
+def timed_renders(pt, n, time_extend=False):
+    """n complete renders back to back; returns (seconds, stats of the last one, summed rays, summed extend ms, timed launches)."""
+    import torch
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rays = launches = 0
+    ext_ms = 0.0
+    for _ in range(n):
+        pt.reset()
+        rs = pt.run(time_extend=time_extend)
+        rays += rs.total_rays; ext_ms += rs.extend_ms; launches += rs.extend_launches
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, rs, rays, ext_ms, launches
 
 
 def main():
@@ -43,8 +70,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--fast", action="store_true", help="fast mode: 4-wide BVH traversal (pt_set_traversal_mode; outside the bit-exact contract, reported separately)")
-    ap.add_argument("--no-extend-timing", action="store_true", help="leave the HIP events around the extend launches out (roofline fields become 0)")
-    ap.add_argument("--config", default="cornell", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default="sphere", choices=sorted(CONFIGS))
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--spp", type=int, default=0)
@@ -53,8 +79,10 @@ def main():
                          "on MI355X, one pool of 2,000,000 the best single pool (profiles/r01_pool_size_sweep_v3.json)")
     ap.add_argument("--pools", type=int, default=3,
                     help="independent path pools per GPU, --paths slots each, driven together on their own streams (pt_render_run_many)")
+    ap.add_argument("--roofline-paths", type=int, default=2_000_000, help="slots of the single pool of the exclusive roofline pass")
+    ap.add_argument("--no-extras", action="store_true", help="skip the exclusive roofline pass, the reference-shaped pool and the configs[1] render")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=64, help="spp of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-spp", type=int, default=32, help="spp of the bounded CPU-baseline sample")
     ap.add_argument("--png", default="", help="write the tonemapped frame of the last step here (rank 0)")
     args = ap.parse_args()
 
@@ -81,18 +109,14 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     pta = importlib.import_module("path-tracer_amd")
-    factory, kwargs, w, h, spp = CONFIGS[args.config]
+    _, _, w, h, spp, cfg_index = CONFIGS[args.config]
     w, h, spp = args.width or w, args.height or h, args.spp or spp
-    desc = getattr(pta.scenes, factory)(**kwargs)
 
     stream = torch.cuda.current_stream().cuda_stream
     dev = pta.request_device(gpu, stream=stream)
     if args.fast:
         dev.call("pt_set_traversal_mode", pta.capi.PT_TRAVERSAL_WIDE)
-    t0 = time.time()
-    scene = pta.scenes.populate(pta.init_scene(dev), desc)
-    scene.build()
-    build_s = time.time() - t0
+    desc, scene, build_s = build_scene(pta, dev, args.config)
     info = scene.info()
 
     # per-GPU share: full spp each, distinct ticket range and RNG streams
@@ -106,37 +130,36 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def one_step(timed, count):
+    def one_step():
         pt.reset()
-        rs = pt.run(time_extend=timed, count_bytes=count)
+        rs = pt.run()
         pta.multigpu.reduce_image(image, dst=0)                # RCCL over xGMI: W*H*4 floats (no-op at N=1)
+        if world > 1:
+            # The reduce runs on RCCL's own stream; the next render's reset zeroes this same buffer from the pools' streams.
+            # Make the order explicit instead of leaning on NULL-stream semantics: the host waits for the reduce.
+            torch.cuda.synchronize()
         return rs
 
-    trav_bytes = 0
-    for i in range(max(args.warmup, 1)):       # the first warm-up render also counts algorithmic bytes (counting kernel variant)
-        rs = one_step(False, i == 0)
-        if i == 0:
-            trav_bytes = rs.traversal_bytes
+    for _ in range(args.warmup):
+        one_step()
     barrier()
     t0 = time.perf_counter()
-    rays = samples = launches = 0
-    extend_ms = 0.0
+    rays = samples = wasted = 0
     for _ in range(args.steps):
-        rs = one_step(not args.no_extend_timing, False)
-        rays += rs.total_rays; samples += rs.total_samples; extend_ms += rs.extend_ms; launches += rs.extend_launches
+        rs = one_step()
+        rays += rs.total_rays; samples += rs.total_samples; wasted += rs.wasted_rays
         steps_per_render = rs.steps
-        launches_per_render = sum(r.steps for r in pt.last_pool_stats) if args.pools > 1 else rs.steps   # extend launches of all pools
         if rs.stack_overflows:
             raise SystemExit(f"traversal guard hit on {rs.stack_overflows} rays")
     barrier()
     elapsed = time.perf_counter() - t0
 
-    tot = torch.tensor([elapsed, float(rays), float(samples)], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([elapsed, float(rays), float(samples), float(wasted)], dtype=torch.float64, device="cuda")
     if world > 1:
         tmax = tot.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         elapsed = float(tmax[0])
-    all_rays, all_samples = float(tot[1]), float(tot[2])
+    all_rays, all_samples, all_wasted = float(tot[1]), float(tot[2]), float(tot[3])
 
     if rank == 0:
         img = image.cpu().numpy().reshape(h, w, 4)
@@ -144,51 +167,123 @@ def main():
         if args.png:
             disp = pta.init_display({"device": dev, "canvas": args.png, "image": {"buffer": image.data_ptr(), "width": w, "height": h}})
             disp.draw()
-        # one extend launch in sixteen is bracketed by HIP events (pt_render_run); mean over those, scaled to all launches
-        all_launches = int(launches_per_render) * args.steps
-        avg_s = extend_ms / 1e3 / max(launches, 1)
-        ext_s = avg_s * all_launches
-        bytes_per_launch = trav_bytes / max(int(launches_per_render), 1)
-        achieved = bytes_per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
+        mode = ", FAST MODE: 4-wide BVH traversal, not bit-exact" if args.fast else ""
         out = {
             "metric": "Mrays/s", "value": round(all_rays / elapsed / 1e6, 3), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {info.n_tris} tris / {info.n_objects} instances, {w}x{h}, {spp} spp per GPU, "
-                                   f"{args.pools} pool(s) of {args.paths} path slots (reference: 1 pool of 1000000), reference bounce rules" + (", FAST MODE: 4-wide BVH traversal, not bit-exact" if args.fast else ""), "spp_total": spp * world,
-                       "parallelism": f"spp-split x{world}, RCCL sum-reduce of the accumulation buffer"},
+            "config": {"workload": f"BASELINE configs[{cfg_index}] {args.config}: {info.n_tris} tris / {info.n_objects} instances, {w}x{h}, {spp} spp per GPU, "
+                                   f"{args.pools} pool(s) of {args.paths} path slots (reference: 1 pool of 1000000), reference bounce rules{mode}",
+                       "spp_total": spp * world, "parallelism": f"spp-split x{world}, RCCL sum-reduce of the accumulation buffer"},
             "samples_per_s": round(all_samples / elapsed, 1),
             "rays_per_render_per_gpu": rays // args.steps, "wavefront_iterations_per_render": int(steps_per_render),
+            # slots that ticket exhaustion has just retired are still pushed to the camera queue and trace one last ray
+            # (logic.js:177-190); they are part of `value`'s ray count, as they are of the reference's ray-trace queue
+            "wasted_rays_per_render_per_gpu": wasted // args.steps, "useful_Mrays_per_s": round((all_rays - all_wasted) / elapsed / 1e6, 3),
             "scene_build_s": round(build_s, 3),
-            "roofline": {"bound": "hbm", "kernel": "k_extend_queue", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(f"{args.config}_{args.pools}x{args.paths}"),
-                         "algorithmic_bytes_per_launch": round(bytes_per_launch, 1),
-                         "avg_launch_us": round(avg_s * 1e6, 3), "launches": all_launches, "launches_timed": launches,
-                         "extend_share_of_step": round(ext_s / elapsed, 4),
-                         "note": "achieved = algorithmic traversal bytes / measured launch time; the kernel also runs the next step's "
-                                 "logic, whose bytes are not counted.  A value above the HBM peak means the scene's nodes are served "
-                                 "from L2/LDS-side caches: `traffic` is what actually crossed the HBM interface.  With several pools the "
-                                 "launches of different pools overlap on the GPU, so a launch's measured time includes the time it shared "
-                                 "the CUs with others (extend_share_of_step can exceed 1); --pools 1 gives the kernel alone"},
         }
+        if not args.no_extras:
+            out["roofline"] = roofline_pass(pta, dev, scene, desc, args, w, h, spp)
+            out["reference_pool_shape"] = reference_shape_pass(pta, dev, scene, desc, w, h, spp)
+            if args.config != "cornell" and not args.fast:
+                out["also"] = {"cornell": other_config_pass(pta, gpu, "cornell", args)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pta, desc, w, h, args.cpu_spp, args.paths)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    pt.destroy()                 # pool contexts borrow dev's scene: they go first
     dev.destroy()
 
 
-def pmc_traffic(config):
-    """HBM-side bytes (reads + writes) per extend launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/traffic_<config>_<pools>x<paths>.json, written by tools/pmc_traffic.py from TCC_EA0_RDREQ{,_32B,_128B} and WRITE_SIZE); None if absent.
-    PMC counters cannot be collected from inside the timed run, so this is the profiled run's figure."""
-    f = os.path.join(ROOT, "profiles", f"traffic_{config}.json")
-    if not os.path.exists(f):
-        return None
-    t = json.load(open(f))
-    return t.get("hbm_bytes_per_launch", t.get("hbm_read_bytes_per_launch"))
+def single_pool(pta, dev, scene, desc, w, h, spp, paths):
+    """One more context on dev's GPU that borrows the built scene and holds ONE pool of `paths` slots with its own image."""
+    d2 = pta.host.Device(sharing=dev)
+    pt = pta.init_path_tracer({"device": d2, "scene": scene, "image": {"width": w, "height": h}, "camera": desc["camera"],
+                               "settings": {"samples": spp, "numPaths": paths}})
+    return d2, pt
+
+
+def roofline_pass(pta, dev, scene, desc, args, w, h, spp):
+    """The extend kernel by itself: one pool (nothing overlaps its launches), one render that counts the algorithmic bytes
+    (counting variant, exact per-ray visit counts), then one render with HIP events on the launch stream around one launch in
+    sixteen.  Which ceiling binds is decided from the committed PMC passes of this same pool shape
+    (profiles/roofline_<config>_1x<paths>.json, tools/pmc_passes.sh + tools/pmc_roofline.py): counters cannot be read inside a timed run."""
+    paths = args.roofline_paths
+    d2, pt = single_pool(pta, dev, scene, desc, w, h, spp, paths)
+    try:
+        rs_c = pt.run(count_bytes=True)
+        sec, rs, rays, ext_ms, timed = timed_renders(pt, 1, time_extend=True)
+    finally:
+        d2.destroy()
+    launches = int(rs.steps)
+    avg_s = ext_ms / 1e3 / max(timed, 1)
+    alg_bytes = rs_c.traversal_bytes / max(launches, 1)
+    alg_gbs = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+    f = os.path.join(ROOT, "profiles", f"roofline_{args.config}_1x{paths}{'_fast' if args.fast else ''}.json")
+    pmc = json.load(open(f)) if os.path.exists(f) else None
+    ceilings = {"hbm_algorithmic": {"achieved": round(alg_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_gbs / HBM_PEAK_GBS, 4),
+                                    "what": "SURVEY 8d bytes (44 + 64 n_inner + 48 n_leaf + 128 (n_enter + n_leave) per ray, exact counts) / launch time: what HBM would have to "
+                                            "deliver if no cache held a node"}}
+    traffic = None
+    if pmc:
+        traffic = pmc["hbm_bytes_per_launch"]
+        t_gbs = traffic / (pmc["rocprof_avg_launch_us"] * 1e-6) / 1e9
+        ceilings["hbm_traffic"] = {"achieved": round(t_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(t_gbs / HBM_PEAK_GBS, 4),
+                                   "what": "bytes that crossed the L2's memory side (TCC_EA0_RDREQ by size + WRITE_SIZE) / the profiled launch time"}
+        ceilings["valu"] = {"achieved": round(pmc["valu_busy"], 4), "peak": 1.0, "unit": "share of SIMD cycles with a VALU instruction active", "frac": round(pmc["valu_busy"], 4),
+                            "what": "SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * GRBM_GUI_ACTIVE / 8) over the whole launch, idle tail included; "
+                                    f"{pmc['valu_insts_per_launch'] / 1e6:.1f} M VALU instructions per launch"}
+    # the binding ceiling: the one the kernel is closest to, among those it cannot exceed (hbm_algorithmic can, when caches serve the nodes)
+    cand = {k: v for k, v in ceilings.items() if k != "hbm_algorithmic" or v["frac"] <= 1.0}
+    bound = max(cand, key=lambda k: cand[k]["frac"])
+    b = ceilings[bound]
+    res = {"kernel": "k_extend_queue", "bound": {"hbm_algorithmic": "hbm", "hbm_traffic": "hbm", "valu": "valu"}[bound], "ceiling": bound,
+           "achieved": b["achieved"], "peak": b["peak"], "unit": b["unit"], "frac": b["frac"], "traffic": traffic,
+           "timing": f"exclusive pass after the timed region: 1 pool of {paths} slots (launches of one pool never overlap), HIP events on the launch stream around 1 launch in 16",
+           "avg_launch_us": round(avg_s * 1e6, 3), "launches_per_render": launches, "launches_timed": int(timed),
+           "kernel_time_per_render_ms": round(avg_s * launches * 1e3, 3), "render_ms": round(sec * 1e3, 3),
+           "Mrays_per_s": round(rays / sec / 1e6, 3), "algorithmic_bytes_per_launch": round(alg_bytes, 1),
+           "ceilings": ceilings}
+    if pmc:
+        res.update({"rocprof_avg_launch_us": pmc["rocprof_avg_launch_us"], "occupancy": pmc["occupancy"], "l1_hit": pmc["l1_hit"], "l2_hit": pmc["l2_hit"],
+                    "wait_on_data_share_of_wave_time": pmc["wait_on_data_share_of_wave_time"],
+                    "sources": [os.path.relpath(f, ROOT)] + [f"profiles/{s}" for s in pmc["sources"]]})
+    else:
+        res["sources"] = []
+        res["note"] = f"no committed PMC passes for this pool shape ({os.path.relpath(f, ROOT)} absent): only the algorithmic ceiling is known"
+    return res
+
+
+def reference_shape_pass(pta, dev, scene, desc, w, h, spp):
+    """The same frame with the reference's own pool: one pool of NUM_PATHS = 1,000,000 slots (path-tracer.js:4)."""
+    d2, pt = single_pool(pta, dev, scene, desc, w, h, spp, 1_000_000)
+    try:
+        pt.run()
+        sec, rs, rays, _, _ = timed_renders(pt, 1)
+    finally:
+        d2.destroy()
+    return {"pools": 1, "paths": 1_000_000, "Mrays_per_s": round(rays / sec / 1e6, 3), "ms_per_render": round(sec * 1e3, 3),
+            "wavefront_iterations_per_render": int(rs.steps)}
+
+
+def other_config_pass(pta, gpu, name, args):
+    """BASELINE configs[1] (the Cornell box) with the same pools, on a context of its own: 1 warm-up + 3 timed renders."""
+    _, _, w, h, spp, idx = CONFIGS[name]
+    dev = pta.request_device(gpu)
+    try:
+        desc, scene, _ = build_scene(pta, dev, name)
+        info = scene.info()
+        pt = pta.init_path_tracer({"device": dev, "scene": scene, "image": {"width": w, "height": h}, "camera": desc["camera"],
+                                   "settings": {"samples": spp, "numPaths": args.paths, "pools": args.pools}})
+        pt.run()
+        sec, rs, rays, _, _ = timed_renders(pt, 3)
+        pt.destroy()
+    finally:
+        dev.destroy()
+    return {"workload": f"BASELINE configs[{idx}] {name}: {info.n_tris} tris / {info.n_objects} instances, {w}x{h}, {spp} spp, {args.pools} pool(s) of {args.paths} path slots",
+            "Mrays_per_s": round(rays / sec / 1e6, 3), "ms_per_render": round(sec / 3 * 1e3, 3), "renders": 3}
 
 
 def cpu_baseline(pta, desc, w, h, spp, paths):

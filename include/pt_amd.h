@@ -164,6 +164,8 @@ typedef struct {
     double  extend_ms;          /* sum of the durations (HIP events) of the timed extend launches: one launch in sixteen */
     int64_t extend_launches;    /* how many launches were timed */
     int64_t traversal_bytes;    /* algorithmic bytes if counted, else 0 */
+    int64_t wasted_rays;        /* part of total_rays: rays traced for slots that ticket exhaustion had just retired
+                                   (logic.js:177-190 pushes them to the camera queue regardless); one per retired slot */
 } pt_run_stats;
 enum { PT_RUN_TIME_EXTEND = 1, PT_RUN_COUNT_BYTES = 2 };
 /* The reference's requestAnimationFrame loop (main.js:61-72) made headless: step until both

@@ -397,8 +397,10 @@ static inline void switch_space(const float m[3][4], v3* o, v3* d, float* hit_di
 /* scene.js:313-475 intersect_bvh.  Differences, both guards the WGSL gets from its runtime:
  * stack has ORC_STACK_SIZE entries (reference 32) and a push onto a full stack ends the traversal
  * with the hit found so far (WGSL: out-of-bounds store is clamped/discarded, then garbage). */
-static hit_res intersect_bvh(const orc_scene* s, v3 o, v3 d) {
-    int32_t stack[ORC_STACK_SIZE];
+/* rec (optional, tools/ only): one byte per trip through the loop -- 1 inner node, 2 triangle, 4 object entered, +8 when the
+ * trip began by leaving an object; a final lone 8 is the leave after the loop.  At most cap bytes; *n_rec gets the true count. */
+static hit_res intersect_bvh_rec(const orc_scene* s, v3 o, v3 d, uint8_t* rec, int cap, int* n_rec) {
+    int32_t stack[ORC_STACK_SIZE]; int nr = 0;
     float hit_dist = 1e6f; int32_t hit_obj = -1, hit_tri = -1;
     int32_t stack_ptr = 0, node_idx = 0, obj_idx = -1, switch_pt = -1;
     hit_res R; memset(&R, 0, sizeof R);
@@ -406,10 +408,13 @@ static hit_res intersect_bvh(const orc_scene* s, v3 o, v3 d) {
     while (stack_ptr >= 0) {
         /* guard: the degenerate N=1 tree (r_child = 0 self pointer, SURVEY "Degenerate N=1") can loop */
         if (++iter > ORC_MAX_ITERS) { R.overflow = 1; break; }
+        uint8_t kind = 0;
         if (stack_ptr < switch_pt) {
             switch_space(s->objects[obj_idx].l2w, &o, &d, &hit_dist);
-            switch_pt = -1; obj_idx = -1; R.n_leave++;
+            switch_pt = -1; obj_idx = -1; R.n_leave++; kind = 8;
         }
+        kind |= node_idx >= 0 ? 1 : (obj_idx < 0 ? 4 : 2);
+        if (rec) { if (nr < cap) rec[nr] = kind; nr++; }
         if (node_idx < 0) {
             if (obj_idx < 0) {
                 obj_idx = -(node_idx + 1);
@@ -446,9 +451,22 @@ static hit_res intersect_bvh(const orc_scene* s, v3 o, v3 d) {
     if (obj_idx >= 0) { /* :442-466 */
         switch_space(s->objects[obj_idx].l2w, &o, &d, &hit_dist);
         R.n_leave++;
+        if (rec) { if (nr < cap) rec[nr] = 8; nr++; }
     }
+    if (n_rec) *n_rec = nr;
     R.hit_obj = hit_obj; R.hit_tri = hit_tri; R.hit_dis = hit_dist;
     return R;
+}
+static hit_res intersect_bvh(const orc_scene* s, v3 o, v3 d) { return intersect_bvh_rec(s, o, d, NULL, 0, NULL); }
+/* the kind of every trip of every ray (see intersect_bvh_rec): kinds[i * cap ..], len[i] = trips of ray i (may exceed cap) */
+void orc_trace_kinds(const orc_scene* s, const float* o3, const float* d3, int64_t n, uint8_t* kinds, int cap, int32_t* len, int threads) {
+    if (threads < 1) threads = 1;
+#pragma omp parallel for schedule(dynamic, 256) num_threads(threads)
+    for (int64_t i = 0; i < n; i++) {
+        int nr = 0;
+        intersect_bvh_rec(s, v3_ld(o3 + 3 * i), v3_ld(d3 + 3 * i), kinds + i * (int64_t)cap, cap, &nr);
+        len[i] = nr;
+    }
 }
 
 static int g_last_max_depth = 0;   /* deepest stack of the last orc_trace_rays call (tests: is the spill exercised?) */

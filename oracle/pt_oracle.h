@@ -82,6 +82,9 @@ const int32_t*    orc_scene_mesh_perm(const orc_scene*, int mesh);   /* per-mesh
 int64_t orc_trace_rays(const orc_scene*, const float* o3, const float* d3, int64_t n,
                        int32_t* hit_obj, int32_t* hit_tri, float* hit_dist, int32_t* counts4, int threads);
 int orc_trace_max_depth(void);   /* deepest traversal stack seen by the last orc_trace_rays call */
+/* tools/ only (wave-scheduling models): the kind of every trip of every ray's walk -- 1 inner node, 2 triangle, 4 object entered,
+ * +8 when the trip began by leaving an object, a final lone 8 = the leave after the loop.  kinds: n x cap bytes; len[i] may exceed cap. */
+void orc_trace_kinds(const orc_scene*, const float* o3, const float* d3, int64_t n, uint8_t* kinds, int cap, int32_t* len, int threads);
 /* independent pin: test every instance x every triangle, no BVH. ties -> first in (obj,tri) order */
 void orc_brute_force(const orc_scene*, const float* o3, const float* d3, int64_t n,
                      int32_t* hit_obj, int32_t* hit_tri, float* hit_t_world, int threads);

@@ -35,7 +35,7 @@ class PtStepStats(C.Structure):
 class PtRunStats(C.Structure):
     _fields_ = [("steps", C.c_int64), ("total_rays", C.c_int64), ("total_samples", C.c_int64),
                 ("stack_overflows", C.c_int64), ("extend_ms", C.c_double), ("extend_launches", C.c_int64),
-                ("traversal_bytes", C.c_int64)]
+                ("traversal_bytes", C.c_int64), ("wasted_rays", C.c_int64)]
 
 
 PT_TRAVERSAL_REFERENCE, PT_TRAVERSAL_WIDE = 0, 1

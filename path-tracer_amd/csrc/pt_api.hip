@@ -711,6 +711,7 @@ int pt_render_run_many(pt_ctx** ctxs, int n, int64_t max_steps, int flags, pt_ru
             unsigned long long v[4] = {0, 0, 0, 0};
             for (int sl = 0; sl < 64; sl++) for (int k = 0; k < 4; k++) v[k] += h.visits[sl][k];
             o->traversal_bytes = count ? (int64_t)(44 * h.total_rays + 64 * v[0] + 48 * v[1] + 128 * (v[2] + v[3])) : 0;
+            o->wasted_rays = h.total_retired;
         }
     }
     return PT_OK;

@@ -66,6 +66,8 @@ struct StepHeader {
                                  // launch writes the next step's while the other workgroups still read this step's)
     int64_t  total_rays;
     int64_t  total_samples;
+    int64_t  total_retired;      // slots retired by ticket exhaustion so far; each traced one wasted ray in the step that retired it
+                                 // (logic.js:177-190: the slot is still pushed to the camera queue)
     unsigned long long overflow; // rays stopped by the stack / iteration guards
     unsigned long long visits[64][4];   // n_inner, n_leaf, n_enter, n_leave (counting variant only), spread over 64 slots
                                         // so that one word does not serialise every wave's atomic; summed by the host

@@ -118,6 +118,11 @@ __global__ __launch_bounds__(PT_BLOCK) void k_compact_generate_shade(PathState p
             hdr->ticket_next[parity ^ 1] = ticket_base + t.z;
             hdr->total_rays += (int64_t)t.x + t.y;
             hdr->total_samples += t.w;
+            {   // tickets at or past the limit retire their slot (below); the slot's camera ray of this step is traced all the same
+                const int64_t first_dead = ticket_base > rc.ticket_limit ? ticket_base : rc.ticket_limit;
+                const int64_t dead = ticket_base + t.z - first_dead;
+                if (dead > 0) hdr->total_retired += dead;
+            }
             if (t.x + t.y == 0 && hdr->first_empty_step < 0) hdr->first_empty_step = hdr->step_index;
             hdr->step_index += 1;
         }

@@ -355,6 +355,9 @@ class PathTracer:
         self.device.call("pt_render_run", int(max_steps), flags, C.byref(rs))
         return rs
 
+    def destroy(self):
+        """Nothing to release (the context owns the buffers); the pooled tracer releases its borrowing contexts here."""
+
     def get_image_buffer(self):
         """path-tracer.js:125-127: the device image buffer (address)."""
         p = C.c_void_p()
@@ -425,7 +428,7 @@ class PooledPathTracer:
         capi.check(lib, self.device.ctx, lib.pt_render_run_many(ctxs, n, int(max_steps), flags, rs), "pt_render_run_many")
         out = capi.PtRunStats()
         out.steps = max(r.steps for r in rs)
-        for f in ("total_rays", "total_samples", "stack_overflows", "extend_launches", "traversal_bytes"):
+        for f in ("total_rays", "total_samples", "stack_overflows", "extend_launches", "traversal_bytes", "wasted_rays"):
             setattr(out, f, sum(getattr(r, f) for r in rs))
         out.extend_ms = sum(r.extend_ms for r in rs)
         self.last_pool_stats = list(rs)

@@ -232,7 +232,7 @@ static napi_value RenderRun(napi_env env, napi_callback_info info) {
     napi_value o; napi_create_object(env, &o);
     set(env, o, "steps", (double)rs.steps); set(env, o, "totalRays", (double)rs.total_rays); set(env, o, "totalSamples", (double)rs.total_samples);
     set(env, o, "stackOverflows", (double)rs.stack_overflows); set(env, o, "extendMs", rs.extend_ms);
-    set(env, o, "extendLaunches", (double)rs.extend_launches); set(env, o, "traversalBytes", (double)rs.traversal_bytes);
+    set(env, o, "extendLaunches", (double)rs.extend_launches); set(env, o, "traversalBytes", (double)rs.traversal_bytes); set(env, o, "wastedRays", (double)rs.wasted_rays);
     return o;
 }
 // renderRunMany([ctx, ...], maxSteps, flags) -> [stats, ...]                [pt_render_run_many]
@@ -249,7 +249,7 @@ static napi_value RenderRunMany(napi_env env, napi_callback_info info) {
         napi_value o; napi_create_object(env, &o);
         set(env, o, "steps", (double)rs[i].steps); set(env, o, "totalRays", (double)rs[i].total_rays); set(env, o, "totalSamples", (double)rs[i].total_samples);
         set(env, o, "stackOverflows", (double)rs[i].stack_overflows); set(env, o, "extendMs", rs[i].extend_ms);
-        set(env, o, "extendLaunches", (double)rs[i].extend_launches); set(env, o, "traversalBytes", (double)rs[i].traversal_bytes);
+        set(env, o, "extendLaunches", (double)rs[i].extend_launches); set(env, o, "traversalBytes", (double)rs[i].traversal_bytes); set(env, o, "wastedRays", (double)rs[i].wasted_rays);
         napi_set_element(env, arr, i, o);
     }
     return arr;

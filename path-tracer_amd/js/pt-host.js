@@ -188,7 +188,7 @@ function initPooledPathTracer(params) {
         const sum = f => rs.reduce((a, r) => a + r[f], 0)
         return { steps: Math.max(...rs.map(r => r.steps)), totalRays: sum("totalRays"), totalSamples: sum("totalSamples"),
                  stackOverflows: sum("stackOverflows"), extendMs: sum("extendMs"), extendLaunches: sum("extendLaunches"),
-                 traversalBytes: sum("traversalBytes"), pools: rs }
+                 traversalBytes: sum("traversalBytes"), wastedRays: sum("wastedRays"), pools: rs }
     }
     function readImage() { let img; for (let k = K - 1; k >= 0; k--) img = pools[k].readImage(); return img }   // each read adds that pool's open tickets
     async function step() {                                                       // every pool takes one step; the sizes add up

@@ -57,6 +57,7 @@ def lib():
             "orc_scene_objects": (vp, [vp]), "orc_scene_tlas_perm": (vp, [vp]), "orc_scene_mesh_perm": (vp, [vp, i32]),
             "orc_trace_rays": (i64, [vp, vp, vp, i64, vp, vp, vp, vp, i32]),
             "orc_trace_max_depth": (i32, []),
+            "orc_trace_kinds": (None, [vp, vp, vp, i64, vp, i32, vp, i32]),
             "orc_brute_force": (None, [vp, vp, vp, i64, vp, vp, vp, i32]),
             "orc_render_create": (vp, [vp, C.POINTER(OrcRenderParams)]), "orc_render_destroy": (None, [vp]),
             "orc_render_set_extensions": (None, [vp, C.POINTER(OrcRenderExt)]),
@@ -145,6 +146,14 @@ class OrcScene:
         self.last_overflow = ov
         self.last_max_depth = lib().orc_trace_max_depth()
         return (ho, ht, hd, cn) if counts else (ho, ht, hd)
+
+    def trace_kinds(self, o, d, cap=512, threads=THREADS):
+        """Per ray, the kind of every trip of its walk (pt_oracle.h orc_trace_kinds): (kinds u8[n, cap], len i32[n])."""
+        o = np.ascontiguousarray(o, np.float32).reshape(-1, 3); d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
+        n = o.shape[0]
+        kinds, ln = np.zeros((n, cap), np.uint8), np.empty(n, np.int32)
+        lib().orc_trace_kinds(self.h, _p(o), _p(d), n, _p(kinds), cap, _p(ln), threads)
+        return kinds, ln
 
     def brute_force(self, o, d, threads=THREADS):
         o = np.ascontiguousarray(o, np.float32).reshape(-1, 3); d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)

@@ -148,6 +148,8 @@ def test_full_render_matches_oracle(pta, orc, device, built, name, w, h, spp, pa
     steps, rays, byts = orr.run()
     assert (rs.steps, rs.total_rays, rs.traversal_bytes, rs.stack_overflows) == (steps, rays, byts, 0)
     assert rs.total_samples == w * h * spp
+    # wasted rays: every slot is retired once by ticket exhaustion and traces one last ray in that step (logic.js:177-190)
+    assert rs.wasted_rays == int((pt.field("flags") >> 31).sum()) == int((orr.field("flags") >> 31).sum()) == paths
     img_g, img_c = pt.read_image(), orr.image()
     np.testing.assert_array_equal(img_g[..., 3], np.full((h, w), spp, np.float32))
     np.testing.assert_array_equal(img_g[..., 3], img_c[..., 3])
