@@ -140,8 +140,10 @@ int pt_render_reset(pt_ctx* ctx);
  *              reference's unknown-id behaviour (zero BRDF)
  *                PT_MAT_LAMBERT  rgb albedo (linear), the reference's cosine sampling
  *                PT_MAT_EMITTER  the path ends at the hit and adds throughput * emission
- *                PT_MAT_MIRROR   wi = d - 2 (d.n) n, throughput *= albedo */
-enum { PT_MAT_LAMBERT = 0, PT_MAT_EMITTER = 1, PT_MAT_MIRROR = 2, PT_MAX_EXT_MATERIALS = 14 };
+ *                PT_MAT_MIRROR   wi = d - 2 (d.n) n, throughput *= albedo
+ *                PT_MAT_GLOSSY   a mirror blurred by roughness = emission[0] in [0, 1] towards the cosine lobe about the normal that
+ *                                faces the ray: wi = normalize(reflect * (1 - roughness) + cosine_sample * roughness), throughput *= albedo */
+enum { PT_MAT_LAMBERT = 0, PT_MAT_EMITTER = 1, PT_MAT_MIRROR = 2, PT_MAT_GLOSSY = 3, PT_MAX_EXT_MATERIALS = 14 };
 typedef struct { float albedo[3]; int32_t type; float emission[3]; int32_t pad; } pt_material;   /* 32 B */
 typedef struct { int32_t max_nb; uint32_t seed; int32_t n_materials, pad; pt_material materials[PT_MAX_EXT_MATERIALS]; } pt_render_ext;
 int pt_render_set_extensions(pt_ctx* ctx, const pt_render_ext* ext);
@@ -210,7 +212,7 @@ int pt_set_traversal_mode(pt_ctx* ctx, int mode);
 /* The extend stage exists in several variants that differ in ray-to-lane mapping and stack placement, never in
  * results.  pt_extend_variants returns how many there are and copies the name of `variant`. */
 int pt_extend_variants(pt_ctx* ctx, int variant, char* name_out, size_t name_cap);
-int pt_set_extend_variant(pt_ctx* ctx, int variant);      /* also: environment PT_EXTEND_VARIANT at pt_create */
+int pt_set_extend_variant(pt_ctx* ctx, int variant);      /* -1 (default): the library picks per scene; also: environment PT_EXTEND_VARIANT at pt_create */
 /* Re-run the extend kernel `reps` times on the ray queue of the last step (idempotent) and report its mean
  * duration in microseconds: A/B of variants on identical work inside one process. */
 int pt_extend_replay(pt_ctx* ctx, int variant, int reps, double* avg_us);

@@ -674,7 +674,7 @@ static void material_slot(orc_render* r, int32_t path) {
         bp[0] = bp[1] = bp[2] = a; bp[3] = wi.z;
     }
     v3 nd = v3_add(v3_add(v3_scale(o1, wi.x), v3_scale(o2, wi.y)), v3_scale(n, wi.z));
-    uint32_t flag = 1u;
+    uint32_t flag = 1u; v3 off_n = n;
     if (mat >= 2 && mat - 2 < r->ext.n_materials) {              /* ext materials (pt_oracle.h); nothing of the reference below */
         const orc_material* m = &r->ext.materials[mat - 2];
         if (m->type == ORC_MAT_LAMBERT) {
@@ -693,12 +693,26 @@ static void material_slot(orc_render* r, int32_t path) {
             float k = 2.0f * v3_dot(d, n);
             nd = v3_sub(d, v3_scale(n, k));
             bp[0] = m->albedo[0]; bp[1] = m->albedo[1]; bp[2] = m->albedo[2]; bp[3] = 1.0f;
+        } else if (m->type == ORC_MAT_GLOSSY) {                  /* rule: pt_oracle.h */
+            float r0, r1; orc_rand2(seed, &r0, &r1); seed += 2.0f;
+            float rad = sqrtf(fmaxf(r0, 0.0f)), theta = 6.283185307179586f * r1, sn, cs;
+            orc_sincos(theta, &sn, &cs);
+            float dx = rad * cs, dy = rad * sn;
+            float z = sqrtf(fmaxf(0.0f, (1.0f - dx * dx) - dy * dy));
+            float dn = v3_dot(d, n);
+            v3 ns = dn < 0.0f ? n : V3(-n.x, -n.y, -n.z);
+            v3 refl = v3_sub(d, v3_scale(n, 2.0f * dn));
+            v3 dd = v3_add(v3_add(v3_scale(o1, dx), v3_scale(o2, dy)), v3_scale(ns, z));
+            float rough = fminf(fmaxf(m->emission[0], 0.0f), 1.0f), keep = 1.0f - rough;
+            nd = v3_normalize(v3_add(v3_scale(refl, keep), v3_scale(dd, rough)));
+            bp[0] = m->albedo[0]; bp[1] = m->albedo[1]; bp[2] = m->albedo[2]; bp[3] = 1.0f;
+            off_n = ns;
         }
     }
     memcpy(r->material_throughput_pdf + 4 * path, bp, 16);
     r->flags[path] |= flag;
     r->random_seed[path] = seed;
-    v3 no = v3_add(hit_pos, v3_scale(n, 0.0001f));
+    v3 no = v3_add(hit_pos, v3_scale(off_n, 0.0001f));           /* material.js:118 */
     float* po = r->path_o + 4 * path; float* pd = r->path_d + 4 * path;
     po[0] = no.x; po[1] = no.y; po[2] = no.z; pd[0] = nd.x; pd[1] = nd.y; pd[2] = nd.z;
 }

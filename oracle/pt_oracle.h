@@ -110,8 +110,12 @@ typedef struct { int64_t n_camera, n_material, n_rays, n_live; } orc_step_stats;
  *   an id with no entry keeps the reference's behaviour for unknown ids: zero BRDF, the path dies)
  *     type 0 Lambert, rgb albedo already in linear space (same cosine sampling as the reference)
  *     type 1 emitter: the path ends at the hit and adds throughput * emission
- *     type 2 mirror: wi = d - 2 (d.n) n, throughput *= albedo */
-enum { ORC_MAT_LAMBERT = 0, ORC_MAT_EMITTER = 1, ORC_MAT_MIRROR = 2, ORC_MAX_EXT_MATERIALS = 14 };
+ *     type 2 mirror: wi = d - 2 (d.n) n, throughput *= albedo
+ *     type 3 glossy: a mirror blurred by `roughness` = emission[0] clamped to [0, 1] (0 = the mirror, 1 = the Lambert lobe):
+ *            ns = the normal turned towards the incoming ray; dd = a cosine-sampled direction about ns (rand2(seed), seed += 2, the
+ *            reference's sampler and basis); wi = normalize(reflect(d, n) * (1 - roughness) + dd * roughness); throughput *= albedo;
+ *            the new origin is offset along ns (every other material keeps the reference's offset along n, material.js:118) */
+enum { ORC_MAT_LAMBERT = 0, ORC_MAT_EMITTER = 1, ORC_MAT_MIRROR = 2, ORC_MAT_GLOSSY = 3, ORC_MAX_EXT_MATERIALS = 14 };
 typedef struct { float albedo[3]; int32_t type; float emission[3]; int32_t pad; } orc_material;       /* 32 B */
 typedef struct { int32_t max_nb; uint32_t seed; int32_t n_materials, pad; orc_material materials[ORC_MAX_EXT_MATERIALS]; } orc_render_ext;
 

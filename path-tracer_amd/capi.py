@@ -40,7 +40,7 @@ class PtRunStats(C.Structure):
 
 PT_TRAVERSAL_REFERENCE, PT_TRAVERSAL_WIDE = 0, 1
 PT_TRACE_NOALLOC_MAX_RAYS = 4194304
-PT_MAT_LAMBERT, PT_MAT_EMITTER, PT_MAT_MIRROR, PT_MAX_EXT_MATERIALS = 0, 1, 2, 14
+PT_MAT_LAMBERT, PT_MAT_EMITTER, PT_MAT_MIRROR, PT_MAT_GLOSSY, PT_MAX_EXT_MATERIALS = 0, 1, 2, 3, 14
 
 
 class PtMaterial(C.Structure):

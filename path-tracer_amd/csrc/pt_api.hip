@@ -77,6 +77,8 @@ struct pt_ctx {
     StepHeader* d_hdr = nullptr; StepHeader* h_hdr = nullptr; int nblocks = 0; int64_t step = 0;
     bool overlapped = false;    // the last pt_render_run_many drove this context together with others
     int64_t known_rays = -1;    // queue size in the last header the host has seen (-1: none yet); picks the compaction kernel's shape
+    int64_t rays_cap = INT64_MAX;   // an upper bound of every coming step's queue length: the pool size, and once a header shows the
+                                    // tickets used up, that header's queue length (retired slots never come back: the queue only shrinks)
     float4* d_ext_mats = nullptr; int n_ext_mats = 0;   // extension materials (pt_render_set_extensions)
     float4* d_wide = nullptr; int traversal_mode = 0;   // fast mode (pt_set_traversal_mode): 4-wide collapse of the packed BLAS
     std::vector<std::pair<void*, size_t>> render_allocs; std::vector<hipEvent_t> events; int64_t ticket_begin = 0;
@@ -145,6 +147,10 @@ int scene_stack_bound(pt_ctx* c) {
     c->stack_bound = (int32_t)std::min<int64_t>(bound + deepest, INT32_MAX);
     return PT_OK;
 }
+
+// Both: 8 waves/SIMD, class of the longest wave first, a tiny scene staged in LDS.  The kind-scheduled walk (4) pays where rays
+// switch between objects (+3...8 % measured with 2 to 101 objects) and costs 12 % on a one-object scene (pt_kernels_extend.hip).
+int extend_variant_of(const pt_ctx* c) { return c->extend_variant >= 0 ? c->extend_variant : (c->n_objects > 1 ? 4 : 3); }
 
 SceneView scene_view(const pt_ctx* c) {
     SceneView v; v.tlas = c->d_tlas_nodes; v.objects = c->d_objects; v.blas = c->d_blas_nodes; v.tris = c->d_tri_records;
@@ -237,8 +243,8 @@ void enqueue_step(pt_ctx* c, int count_visits, hipEvent_t ev0, hipEvent_t ev1) {
     if (shape) fat = shape == 2;
     ptk_count_compact_generate_shade(c->ps, c->rc, sv, c->d_code, c->d_blk_counts, parity, c->d_hdr, c->d_cam_q, c->d_mat_q, fat, c->stream);
     if (ev0) (void)hipEventRecord(ev0, c->stream);
-    ptk_extend_queue(c->ps, c->rc, sv, c->d_hdr, c->d_cam_q, c->d_mat_q, c->d_spill, count_visits, c->extend_variant, nullptr, c->d_image, c->d_code,
-                     (unsigned long long*)c->d_blk_counts + (parity ^ 1), c->stream);
+    ptk_extend_queue(c->ps, c->rc, sv, c->d_hdr, c->d_cam_q, c->d_mat_q, c->d_spill, count_visits, extend_variant_of(c), nullptr, c->d_image, c->d_code,
+                     (unsigned long long*)c->d_blk_counts + (parity ^ 1), (int)std::min<int64_t>(c->rays_cap, c->rc.num_paths), c->stream);
     if (ev1) (void)hipEventRecord(ev1, c->stream);
     c->step++;
 }
@@ -255,6 +261,12 @@ int build_wide(pt_ctx* c) {
     return PT_OK;
 }
 
+// what the host learns from a header it has read back
+void note_header(pt_ctx* c, const StepHeader& h) {
+    c->known_rays = h.n_rays;
+    if (h.pixel_counter >= c->rc.ticket_limit) c->rays_cap = std::min<int64_t>(c->rays_cap, h.n_rays);
+}
+
 // fresh StepHeader: no step taken, ticket counter at this GPU's first ticket
 int write_header(pt_ctx* c) {
     HIPOK(c, hipStreamSynchronize(c->stream));
@@ -263,7 +275,7 @@ int write_header(pt_ctx* c) {
     *c->h_hdr = h;
     HIPOK(c, hipMemcpyAsync(c->d_hdr, c->h_hdr, sizeof h, hipMemcpyHostToDevice, c->stream));
     HIPOK(c, hipStreamSynchronize(c->stream));
-    c->step = 0; c->known_rays = -1;
+    c->step = 0; c->known_rays = -1; c->rays_cap = INT64_MAX;
     return PT_OK;
 }
 
@@ -287,7 +299,7 @@ int pt_create(int device_id, pt_ctx** out) {
         return fail(nullptr, PT_ERR_HIP, std::string("pt_create: hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
     }
     c->own_stream = true;
-    c->extend_variant = 3;   // 8 waves/SIMD, class of the longest wave first, a tiny scene staged in LDS (tools/extend_ab.py)
+    c->extend_variant = -1;  // automatic: variant 4 (kind-scheduled walk) for scenes with several objects, else 3 (scene_view)
     if (const char* v = getenv("PT_EXTEND_VARIANT")) c->extend_variant = atoi(v);
     *out = c;
     return PT_OK;
@@ -583,7 +595,7 @@ int pt_render_set_extensions(pt_ctx* c, const pt_render_ext* e) {
     if (c->step != 0) return fail(c, PT_ERR_STATE, "pt_render_set_extensions: the render has started; call pt_render_reset first");
     if (e->max_nb < 0 || e->max_nb > PT_MAX_NB_LIMIT || e->n_materials < 0 || e->n_materials > PT_MAX_EXT_MATERIALS) return fail(c, PT_ERR_ARG, "pt_render_set_extensions: bad max_nb or n_materials");
     for (int k = 0; k < e->n_materials; k++)
-        if (e->materials[k].type < 0 || e->materials[k].type > PT_MAT_MIRROR) return fail(c, PT_ERR_ARG, "pt_render_set_extensions: unknown material type");
+        if (e->materials[k].type < 0 || e->materials[k].type > PT_MAT_GLOSSY) return fail(c, PT_ERR_ARG, "pt_render_set_extensions: unknown material type");
     HIPOK(c, hipSetDevice(c->device));
     c->rc.max_nb = e->max_nb > 0 ? e->max_nb : 20;
     c->rc.seed_mix = e->seed * 0x9E3779B1u;
@@ -616,7 +628,7 @@ int pt_render_step(pt_ctx* c, pt_step_stats* stats) {
         int r = read_back(c, c->h_hdr, c->d_hdr, sizeof(StepHeader));
         if (r) return r;
         stats->n_camera = c->h_hdr->n_camera; stats->n_material = c->h_hdr->n_material; stats->n_rays = c->h_hdr->n_rays;
-        c->known_rays = c->h_hdr->n_rays;
+        note_header(c, *c->h_hdr);
         stats->step_index = c->step - 1;
     }
     return PT_OK;
@@ -688,7 +700,7 @@ int pt_render_run_many(pt_ctx** ctxs, int n, int64_t max_steps, int flags, pt_ru
             if (s.done) continue;
             pt_ctx* c = s.c;
             if ((r = run_collect(s, b))) return r;
-            c->known_rays = c->h_hdr[b & 1].n_rays;
+            note_header(c, c->h_hdr[b & 1]);
             if (c->h_hdr[b & 1].first_empty_step >= 0 || !s.more) {
                 if (s.last > b && (r = run_collect(s, s.last))) return r;    // drain the batch issued ahead
                 s.done = true;
@@ -805,7 +817,7 @@ int pt_extend_variants(pt_ctx* c, int variant, char* name_out, size_t name_cap) 
 }
 
 int pt_set_extend_variant(pt_ctx* c, int variant) {
-    if (!c || variant < 0 || variant >= ptk_extend_num_variants()) return fail(c, PT_ERR_ARG, "pt_set_extend_variant: no such variant");
+    if (!c || variant < -1 || variant >= ptk_extend_num_variants()) return fail(c, PT_ERR_ARG, "pt_set_extend_variant: no such variant");
     c->extend_variant = variant;
     return PT_OK;
 }
@@ -819,7 +831,7 @@ int pt_extend_replay(pt_ctx* c, int variant, int reps, double* avg_us) {
     double total_ms = 0;
     for (int i = 0; i < reps; i++) {   // the kernel only reads path_o/path_d and rewrites the same hit_obj/hit_tri: idempotent
         HIPOK(c, hipEventRecord(e0, c->stream));
-        ptk_extend_queue(c->ps, c->rc, sv, c->d_hdr, c->d_cam_q, c->d_mat_q, c->d_spill, 0, variant, nullptr, nullptr, nullptr, nullptr, c->stream);
+        ptk_extend_queue(c->ps, c->rc, sv, c->d_hdr, c->d_cam_q, c->d_mat_q, c->d_spill, 0, variant, nullptr, nullptr, nullptr, nullptr, c->rc.num_paths, c->stream);
         HIPOK(c, hipEventRecord(e1, c->stream));
         HIPOK(c, hipEventSynchronize(e1));
         float ms = 0; HIPOK(c, hipEventElapsedTime(&ms, e0, e1)); total_ms += ms;
@@ -839,7 +851,7 @@ int pt_extend_wave_log(pt_ctx* c, int variant, uint64_t* out, int64_t cap_waves,
     unsigned long long* d_log = nullptr; int r; Tmp tmp;
     if ((r = tmp.alloc(c, &d_log, (size_t)n * 4, true))) return r;
     SceneView sv = scene_view(c);
-    ptk_extend_queue(c->ps, c->rc, sv, c->d_hdr, c->d_cam_q, c->d_mat_q, c->d_spill, 0, variant, d_log, nullptr, nullptr, nullptr, c->stream);
+    ptk_extend_queue(c->ps, c->rc, sv, c->d_hdr, c->d_cam_q, c->d_mat_q, c->d_spill, 0, variant, d_log, nullptr, nullptr, nullptr, c->rc.num_paths, c->stream);
     HIPOK(c, hipGetLastError());
     r = read_back(c, out, d_log, (size_t)n * 32);
     *n_waves = n;

@@ -127,7 +127,8 @@ void ptk_count_compact_generate_shade(const PathState& ps, const RenderConst& rc
 void ptk_extend_queue(const PathState& ps, const RenderConst& rc, const SceneView& sc, StepHeader* hdr,
                       const int32_t* cam_q, const int32_t* mat_q, int32_t* spill, int count, int variant,
                       unsigned long long* wave_log /* null unless measuring */, float* image, uint8_t* code,
-                      unsigned long long* rec_next /* the next step's count records, used with code */, hipStream_t s);   // uses rc.max_nb
+                      unsigned long long* rec_next /* the next step's count records, used with code */,
+                      int grid_rays /* an upper bound of the queue length; the launch holds this many threads */, hipStream_t s);   // uses rc.max_nb
 int64_t ptk_extend_waves(int num_paths, int variant);   // waves the launch of that variant holds (wave_log entries)
 int ptk_extend_num_variants();
 const char* ptk_extend_variant_name(int v);

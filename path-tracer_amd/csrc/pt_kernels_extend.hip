@@ -10,6 +10,7 @@
 // whatever the entry, lanes l / l+32 are served in different LDS cycles: divergent depths never
 // conflict); deeper entries go to an HBM spill laid out [entry][slot] so that equal depths coalesce.
 #include "pt_shading.cuh"
+#include <algorithm>
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int rank_below(unsigned long long mask) {
@@ -175,6 +176,95 @@ __device__ __forceinline__ bool trav_step(const SceneView& sc, Ray& r, const STK
     }
     return r.sp >= 0;
 }
+// --------------------------------------------------------------------------------------------
+// Kind-scheduled traversal (extend variant 4).  The reference's loop does one of four things per trip and lane -- test an inner
+// node's two boxes, test a triangle, enter an object, and, in front of any of them, leave one (scene.js:330-440).  With one ray per
+// lane a wave pays for every kind some lane needs in every trip: all four bodies, one after the other, each under a partial exec
+// mask (measured on the 82 k-triangle mesh: 43 % of the lane slots of the issued vector instructions do work).  Here every lane
+// keeps the kind of its NEXT operation, and each pass through the loop the wave runs ONE body: the one that advances the most lanes
+// per instruction it costs.  A lane's own sequence of operations -- visit order, arithmetic, stack, counts -- is exactly the
+// reference's; only when it runs changes.
+// Measured (profiles/r02_extend_ab_sched_*): each body grows by the bookkeeping (next kind, guard: inner node 95 -> 116 vector
+// instructions, triangle 88 -> 112, one switch body of 182 for the two of 131 + 134), so on identical queues the launch issues MORE
+// vector instructions (+14 % on the 82 k-triangle mesh, +56 % on the one-object 10 M-triangle grid, whose walk is inner nodes and
+// triangles only) -- a model fed with the oracle's per-ray kind sequences had promised 1.4x fewer, by pricing the bodies too low.
+// What it does buy is fewer waits (SQ_WAIT_ANY -14 %): in the full render it is +3...8 % on scenes with several objects and -12 %
+// on the one-object grid, so the library picks it only for scenes with more than one object (pt_api.hip).
+// --------------------------------------------------------------------------------------------
+enum { PT_K_INNER = 0, PT_K_LEAF = 1, PT_K_SWITCH = 2, PT_K_DONE = 3 };
+__device__ __forceinline__ int kind_after(const Ray& r) {
+    if (r.sp < 0) return PT_K_DONE;                             // the loop condition (scene.js:328)
+    if (r.sp < r.switch_pt) return PT_K_SWITCH;                 // :330 the next trip begins by leaving the object
+    if (r.node >= 0) return PT_K_INNER;
+    return r.obj < 0 ? PT_K_SWITCH : PT_K_LEAF;                 // :357 enter / :380 triangle
+}
+// a trip = one INNER, LEAF or entering SWITCH; a leaving SWITCH belongs to the trip that follows it (r.iter counts trips, as in trav_step)
+template <class STK>
+__device__ __forceinline__ bool trip_guard(Ray& r) {
+    r.iter++;
+    if (!STK::shallow && r.iter > PT_MAX_ITERS) { r.overflow = 1; return false; }
+    return true;
+}
+template <bool COUNT, class STK>
+__device__ __forceinline__ int op_inner(const SceneView& sc, Ray& r, const STK& stk) {      // :392-439
+    if (!trip_guard<STK>(r)) return PT_K_DONE;
+    const float4* nd = (r.obj < 0 ? sc.tlas : sc.blas) + 4 * (int64_t)r.node;
+    float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+    if (COUNT) r.n_inner++;
+    float l_dist = slab(F3(q0), F3(q1), r.o, r.id), r_dist = slab(F3(q2), F3(q3), r.o, r.id);
+    bool l_valid = l_dist != -1e30f && l_dist < r.hit_dist;
+    bool r_valid = r_dist != -1e30f && r_dist < r.hit_dist;
+    int l_child = __float_as_int(q0.w), r_child = __float_as_int(q2.w);
+    const bool both = l_valid && r_valid;
+    const bool take_l = l_valid && (!r_valid || l_dist < r_dist);
+    if (both) {
+        if (!STK::shallow && __any(r.sp >= STK::lds_n) && r.sp >= PT_STACK_SIZE) { r.overflow = 1; return PT_K_DONE; }
+        stk.put(r.sp, take_l ? r_child : l_child);
+        r.sp += 1;
+    }
+    r.node = take_l ? l_child : r_child;
+    if (!(l_valid || r_valid)) { r.sp -= 1; r.node = stk.get(r.sp); }
+    return kind_after(r);
+}
+template <bool COUNT, class STK>
+__device__ __forceinline__ int op_leaf(const SceneView& sc, Ray& r, const STK& stk) {       // :380-391
+    if (!trip_guard<STK>(r)) return PT_K_DONE;
+    int t = -(r.node + 1);
+    const float4* tr = sc.tris + 3 * (int64_t)t;
+    float dist = tri_hit(r.o, r.d, tr[0], tr[1], tr[2]);
+    if (dist > 0.0f && dist < r.hit_dist) { r.hit_dist = dist; r.hit_tri = t; r.hit_obj = r.obj; }
+    if (COUNT) r.n_leaf++;
+    r.sp -= 1; r.node = stk.get(r.sp);
+    return kind_after(r);
+}
+// leaving (:330-355, rows 0-2 of the object = localToWorld) and entering (:357-379, rows 4-6 = worldToLocal, row 3 = root and
+// material) run the same arithmetic on different rows: one body serves both groups of lanes
+template <bool COUNT, class STK>
+__device__ __forceinline__ int op_switch(const SceneView& sc, Ray& r) {
+    const bool entering = r.obj < 0;
+    if (entering && !trip_guard<STK>(r)) return PT_K_DONE;
+    const int oi = entering ? -(r.node + 1) : r.obj;
+    const float4* ob = sc.objects + 8 * (int64_t)oi + (entering ? 4 : 0);
+    float4 r0 = ob[0], r1 = ob[1], r2 = ob[2];
+    if (entering) { r.node = __float_as_int(ob[-1].x); r.switch_pt = r.sp; r.obj = oi; if (COUNT) r.n_enter++; }
+    else { r.switch_pt = -1; r.obj = -1; if (COUNT) r.n_leave++; }
+    switch_space(r0, r1, r2, r);
+    return kind_after(r);
+}
+// Runs the walk of every lane of the wave to its end.  `kind`: PT_K_INNER for a lane with a ray, PT_K_DONE for one without.
+template <bool COUNT, class STK>
+__device__ __forceinline__ void traverse_scheduled(const SceneView& sc, Ray& r, const STK& stk, int kind) {
+    for (;;) {
+        const int ci = __popcll(__ballot(kind == PT_K_INNER)), cl = __popcll(__ballot(kind == PT_K_LEAF)), cs = __popcll(__ballot(kind == PT_K_SWITCH));
+        if ((ci | cl | cs) == 0) break;
+        // lanes advanced per instruction issued: the bodies cost about 1 : 1.4 : 2.4 (inner : triangle : switch)
+        const int wi = ci * 12, wl = cl * 9, ws = cs * 5;
+        if (wi >= wl && wi >= ws) { if (kind == PT_K_INNER) kind = op_inner<COUNT, STK>(sc, r, stk); }
+        else if (wl >= ws)        { if (kind == PT_K_LEAF) kind = op_leaf<COUNT, STK>(sc, r, stk); }
+        else                      { if (kind == PT_K_SWITCH) kind = op_switch<COUNT, STK>(sc, r); }
+    }
+}
+
 // scene.js:442-466: a ray that ends inside an object is mapped back to world space
 template <bool COUNT>
 __device__ __forceinline__ void trav_finish(const SceneView& sc, Ray& r) {
@@ -215,7 +305,7 @@ __device__ __forceinline__ void publish(unsigned long long ov, unsigned long lon
 // SCENE_QUADS > 0: a scene whose four buffers together fit in SCENE_QUADS quads (12 per object + 7 per triangle) is copied
 // into LDS by every workgroup and traversed from there: the same records, an LDS read instead of an L1 round trip in
 // every link of the trip's dependent chain.
-template <int LDS_N, int BLOCK, bool COUNT, int ORDER, bool LOG, bool LOGIC, bool WIDE = false, int SCENE_QUADS = 0, bool SHALLOW = false>
+template <int LDS_N, int BLOCK, bool COUNT, int ORDER, bool LOG, bool LOGIC, bool WIDE = false, int SCENE_QUADS = 0, bool SHALLOW = false, bool SCHED = false>
 __global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView sc, StepHeader* hdr, const int32_t* __restrict__ cam_q,
                                                         const int32_t* __restrict__ mat_q, int32_t* spill, int64_t spill_stride,
                                                         unsigned long long* wave_log, float* __restrict__ image, uint8_t* __restrict__ code_out,
@@ -244,15 +334,19 @@ __global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView 
     int q = blk * BLOCK + threadIdx.x;
     Ray r; ray_init(r, F3(0, 0, 1), F3(0, 0, 1));
     unsigned code = 0u; int grp = -1;
+    typedef Stack<LDS_N, BLOCK, SHALLOW> STK;
+    STK stk{s_stack + threadIdx.x, spill + q, spill_stride};
+    int path = -1;
     if (q < n_rays) {
-        int path = q < n_cam ? cam_q[q] : mat_q[q - n_cam];
+        path = q < n_cam ? cam_q[q] : mat_q[q - n_cam];
         f3 ro, rd;
         if (LOGIC && q < n_cam) generate_one(ps, rc, path, ro, rd);          // camera.js:60-118; replays (no LOGIC) re-read the stored ray
         else { ro = F3(ps.path_o[path]); rd = F3(ps.path_d[path]); }
         ray_init(r, ro, rd);
-        typedef Stack<LDS_N, BLOCK, SHALLOW> STK;
-        STK stk{s_stack + threadIdx.x, spill + q, spill_stride};
-        while (trav_step<COUNT, STK, WIDE>(sc, r, stk)) {}
+        if (!SCHED) while (trav_step<COUNT, STK, WIDE>(sc, r, stk)) {}
+    }
+    if (SCHED) traverse_scheduled<COUNT, STK>(sc, r, stk, q < n_rays ? PT_K_INNER : PT_K_DONE);     // the whole wave walks together
+    if (q < n_rays) {
         trav_finish<COUNT>(sc, r);
         ps.hit[path] = make_int2(r.hit_obj, r.hit_tri);
         if (LOGIC) {
@@ -328,14 +422,16 @@ static int64_t pad_to(int64_t n, int64_t m) { return (n + m - 1) / m * m; }
 // The spill is sized for the smallest LDS share any variant uses (12 entries) and the largest slot count.
 size_t ptk_spill_ints(int64_t n_rays) { return (size_t)pad_to(n_rays, 256) * (PT_STACK_SIZE - PT_STAGED_LDS_STACK); }
 
-template <int LDS_N, int BLOCK, int ORDER, bool WIDE = false, int SCENE_QUADS = 0, bool SHALLOW = false>
-static void launch_queue(const PathState& ps, int num_paths, const SceneView& sc, StepHeader* hdr, const int32_t* cam_q,
+template <int LDS_N, int BLOCK, int ORDER, bool WIDE = false, int SCENE_QUADS = 0, bool SHALLOW = false, bool SCHED = false>
+static void launch_queue(const PathState& ps, int num_paths, int grid_rays, const SceneView& sc, StepHeader* hdr, const int32_t* cam_q,
                          const int32_t* mat_q, int32_t* spill, int count, unsigned long long* wave_log, float* image, uint8_t* code,
                          unsigned long long* rec_next, const RenderConst& rc, hipStream_t s) {
     int64_t stride = pad_to(num_paths, 256);
-    dim3 grid((unsigned)((num_paths + BLOCK - 1) / BLOCK));
+    // grid_rays: an upper bound of this step's queue length the host knows (the pool size until the tickets have run out; then
+    // the last queue length it has seen: once no ticket is left, a step's rays are a subset of the step before's)
+    dim3 grid((unsigned)((std::max(1, std::min(num_paths, grid_rays)) + BLOCK - 1) / BLOCK));
     const size_t scene_lds = SCENE_QUADS > 0 ? 16 * (size_t)(12 * sc.n_objects + 7 * sc.n_tris) : 0;
-#define PT_LAUNCH(COUNT, LOG, LOGIC) hipLaunchKernelGGL((k_extend_queue<LDS_N, BLOCK, COUNT, ORDER, LOG, LOGIC, WIDE, SCENE_QUADS, SHALLOW>), grid, dim3(BLOCK), scene_lds, s, ps, sc, hdr, \
+#define PT_LAUNCH(COUNT, LOG, LOGIC) hipLaunchKernelGGL((k_extend_queue<LDS_N, BLOCK, COUNT, ORDER, LOG, LOGIC, WIDE, SCENE_QUADS, SHALLOW, SCHED>), grid, dim3(BLOCK), scene_lds, s, ps, sc, hdr, \
                                                        cam_q, mat_q, spill, stride, wave_log, image, code, rec_next, rc)
     if (wave_log)    PT_LAUNCH(false, true, false);    // measurement replays (code == null): traversal only, idempotent
     else if (!code)  PT_LAUNCH(false, false, false);
@@ -359,25 +455,30 @@ static void launch_queue(const PathState& ps, int num_paths, const SceneView& sc
 // Cornell and 4 % on the 82 k-triangle mesh, so a cheaper exact divide could return at most half of that.
 static const char* kVariantNames[] = {"256-thread workgroups, 24 LDS stack entries", "64-thread workgroups, 16 LDS stack entries",
                                       "64-thread workgroups, 16 LDS entries, class of the longest wave first",
-                                      "as 2; a scene of <= 8 KB is staged in LDS (256-thread workgroups, 12 LDS stack entries)"};
-int ptk_extend_num_variants() { return 4; }
-const char* ptk_extend_variant_name(int v) { return (v >= 0 && v < 4) ? kVariantNames[v] : "?"; }
+                                      "as 2; a scene of <= 8 KB is staged in LDS (256-thread workgroups, 12 LDS stack entries)",
+                                      "as 3, kind-scheduled: each pass of the loop the wave runs the one body (inner node, triangle, object switch) that advances most lanes"};
+int ptk_extend_num_variants() { return 5; }
+const char* ptk_extend_variant_name(int v) { return (v >= 0 && v < 5) ? kVariantNames[v] : "?"; }
 void ptk_extend_queue(const PathState& ps, const RenderConst& rc, const SceneView& sc, StepHeader* hdr, const int32_t* cam_q,
                       const int32_t* mat_q, int32_t* spill, int count, int variant, unsigned long long* wave_log, float* image, uint8_t* code,
-                      unsigned long long* rec_next, hipStream_t s) {
-    if (sc.wide)           launch_queue<16, 64, 2, true>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);   // fast mode
-    else if (variant == 0) launch_queue<24, 256, 1>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
-    else if (variant == 1) launch_queue<16, 64, 1>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
-    else if (variant == 3 && 12 * (int64_t)sc.n_objects + 7 * (int64_t)sc.n_tris <= PT_SCENE_LDS_QUADS) {
-        if (sc.stack_bound <= PT_STAGED_LDS_STACK)      // no ray's stack can leave LDS: no spill path, no overflow guard
-            launch_queue<PT_STAGED_LDS_STACK, 256, 2, false, PT_SCENE_LDS_QUADS, true>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
-        else
-            launch_queue<PT_STAGED_LDS_STACK, 256, 2, false, PT_SCENE_LDS_QUADS>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
+                      unsigned long long* rec_next, int grid_rays, hipStream_t s) {
+    if (sc.wide)           launch_queue<16, 64, 2, true>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);   // fast mode
+    else if (variant == 0) launch_queue<24, 256, 1>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
+    else if (variant == 1) launch_queue<16, 64, 1>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
+    else if (variant >= 3 && 12 * (int64_t)sc.n_objects + 7 * (int64_t)sc.n_tris <= PT_SCENE_LDS_QUADS) {
+        if (sc.stack_bound <= PT_STAGED_LDS_STACK) {    // no ray's stack can leave LDS: no spill path, no overflow guard
+            if (variant == 4) launch_queue<PT_STAGED_LDS_STACK, 256, 2, false, PT_SCENE_LDS_QUADS, true, true>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
+            else launch_queue<PT_STAGED_LDS_STACK, 256, 2, false, PT_SCENE_LDS_QUADS, true>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
+        } else {
+            if (variant == 4) launch_queue<PT_STAGED_LDS_STACK, 256, 2, false, PT_SCENE_LDS_QUADS, false, true>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
+            else launch_queue<PT_STAGED_LDS_STACK, 256, 2, false, PT_SCENE_LDS_QUADS>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
+        }
     }
-    else                   launch_queue<16, 64, 2>(ps, rc.num_paths, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
+    else if (variant == 4) launch_queue<16, 64, 2, false, 0, false, true>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
+    else                   launch_queue<16, 64, 2>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
 }
 int64_t ptk_extend_waves(int num_paths, int variant) {
-    int block = (variant == 0 || variant == 3) ? 256 : 64;   // variant 3 falls back to 64 when the scene does not fit: an upper bound then
+    int block = (variant == 0 || variant >= 3) ? 256 : 64;   // variants 3 and 4 fall back to 64 when the scene does not fit: an upper bound then
     return (int64_t)((num_paths + block - 1) / block) * (block / 64);
 }
 size_t ptk_direct_spill_ints(int64_t n_rays) { return (size_t)pad_to(n_rays, 256) * (PT_STACK_SIZE - PT_LDS_STACK); }

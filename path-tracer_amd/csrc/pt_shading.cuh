@@ -105,7 +105,7 @@ __device__ __forceinline__ void shade_one(const PathState& ps, const SceneView& 
         bp = make_float4(a, a, a, wi.z);
     }
     f3 nd = (o1 * wi.x + o2 * wi.y) + n * wi.z;
-    unsigned flag = 1u;
+    unsigned flag = 1u; f3 off_n = n;
     if (mat >= 2 && mat - 2 < sc.n_ext_mats) {                                  // extension materials: rules defined in oracle/pt_oracle.h
         float4 m0 = sc.ext_mats[2 * (mat - 2)], m1 = sc.ext_mats[2 * (mat - 2) + 1];
         int type = __float_as_int(m0.w);
@@ -124,9 +124,23 @@ __device__ __forceinline__ void shade_one(const PathState& ps, const SceneView& 
             float k = 2.0f * dot3(d, n);
             nd = d - n * k;
             bp = make_float4(m0.x, m0.y, m0.z, 1.0f);
+        } else if (type == 3) {                                                 // glossy: a mirror blurred by roughness = emission[0]
+            float2 r2 = rand2(seed); seed += 2.0f;
+            float rad = __builtin_sqrtf(fmax_(r2.x, 0.0f)), sn, cs;
+            pt_sincos(6.283185307179586f * r2.y, sn, cs);
+            float dx = rad * cs, dy = rad * sn;
+            float z = __builtin_sqrtf(fmax_(0.0f, (1.0f - dx * dx) - dy * dy));
+            float dn = dot3(d, n);
+            f3 ns = dn < 0.0f ? n : F3(-n.x, -n.y, -n.z);
+            f3 refl = d - n * (2.0f * dn);
+            f3 dd = (o1 * dx + o2 * dy) + ns * z;
+            float rough = fmin_(fmax_(m1.x, 0.0f), 1.0f), keep = 1.0f - rough;
+            nd = normalize3(refl * keep + dd * rough);
+            bp = make_float4(m0.x, m0.y, m0.z, 1.0f);
+            off_n = ns;
         }
     }
-    f3 no = hit_pos + n * 0.0001f;
+    f3 no = hit_pos + off_n * 0.0001f;
     ps.material_throughput_pdf[path] = bp;
     ps.state[path] |= flag;
     ps.random_seed[path] = seed;

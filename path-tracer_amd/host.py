@@ -288,13 +288,13 @@ def init_scene(device):
 
 
 # ------------------------------------------------------------------ scripts/render/path-tracer.js
-MATERIAL_TYPES = {"lambert": capi.PT_MAT_LAMBERT, "emitter": capi.PT_MAT_EMITTER, "mirror": capi.PT_MAT_MIRROR}
+MATERIAL_TYPES = {"lambert": capi.PT_MAT_LAMBERT, "emitter": capi.PT_MAT_EMITTER, "mirror": capi.PT_MAT_MIRROR, "glossy": capi.PT_MAT_GLOSSY}
 
 
 def render_ext(settings, cls=None):
     """settings.{maxNb, seed, materials} -> pt_render_ext, or None when none of them is given (the reference has none of
-    these: SURVEY 8f.1).  materials: list of {"type": "lambert"|"emitter"|"mirror", "albedo": [r,g,b], "emission": [r,g,b]}
-    describing material ids 2, 3, ..."""
+    these: SURVEY 8f.1).  materials: list of {"type": "lambert"|"emitter"|"mirror"|"glossy", "albedo": [r,g,b], "emission": [r,g,b],
+    "roughness": x (glossy only; travels in emission[0])} describing material ids 2, 3, ..."""
     if not any(k in settings for k in ("maxNb", "seed", "materials")):
         return None
     ext = (cls or capi.PtRenderExt)()
@@ -307,6 +307,8 @@ def render_ext(settings, cls=None):
         ext.materials[k].type = MATERIAL_TYPES[m["type"]]
         ext.materials[k].albedo[:] = [float(x) for x in m.get("albedo", [0, 0, 0])]
         ext.materials[k].emission[:] = [float(x) for x in m.get("emission", [0, 0, 0])]
+        if m["type"] == "glossy":
+            ext.materials[k].emission[0] = float(m.get("roughness", 0.0))
     return ext
 
 

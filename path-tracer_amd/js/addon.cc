@@ -186,7 +186,7 @@ static napi_value RenderInit(napi_env env, napi_callback_info info) {
     return nullptr;
 }
 // renderSetExtensions(ctx, maxNb, seed, Float32Array mats|null)              [pt_render_set_extensions]
-// mats: 8 floats per extension material (ids 2, 3, ...): albedo r g b, type (0 Lambert, 1 emitter, 2 mirror), emission r g b, 0
+// mats: 8 floats per extension material (ids 2, 3, ...): albedo r g b, type (0 Lambert, 1 emitter, 2 mirror, 3 glossy), emission r g b (glossy: roughness, 0, 0), 0
 static napi_value RenderSetExtensions(napi_env env, napi_callback_info info) {
     napi_value a[4]; if (!get_args(env, info, 4, a)) return nullptr;
     pt_ctx* c = ctx_of(env, a[0]); if (!c) return nullptr;

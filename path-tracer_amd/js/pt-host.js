@@ -147,12 +147,13 @@ function initPathTracer(params) {
         imageOf: s.imageOf,
     })
     // extensions the reference does not have (default-off): settings.maxNb, settings.seed, settings.materials =
-    // [{type: "lambert"|"emitter"|"mirror", albedo: [r,g,b], emission: [r,g,b]}, ...] for material ids 2, 3, ...
+    // [{type: "lambert"|"emitter"|"mirror"|"glossy", albedo: [r,g,b], emission: [r,g,b], roughness: x (glossy)}, ...] for material ids 2, 3, ...
     if (s.maxNb !== undefined || s.seed !== undefined || s.materials !== undefined) {
-        const types = { lambert: 0, emitter: 1, mirror: 2 }, mats = s.materials || [], f = new Float32Array(8 * mats.length)
+        const types = { lambert: 0, emitter: 1, mirror: 2, glossy: 3 }, mats = s.materials || [], f = new Float32Array(8 * mats.length)
         mats.forEach((m, k) => {
             if (!(m.type in types)) throw new Error(`unknown material type ${m.type}`)
             f.set(m.albedo || [0, 0, 0], 8 * k); f[8 * k + 3] = types[m.type]; f.set(m.emission || [0, 0, 0], 8 * k + 4)
+            if (m.type === "glossy") f[8 * k + 4] = m.roughness || 0
         })
         addon().renderSetExtensions(device.ctx, s.maxNb || 0, s.seed || 0, f)
     }

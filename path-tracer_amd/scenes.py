@@ -64,7 +64,7 @@ def cornell_box(single_mesh=False):
 
 def cornell_box_ext():
     """C2's extension variant (no reference counterpart): red / green side walls, a ceiling light, a mirror
-    tall box and a grey short box.  Material ids 2.. index `materials` (settings.materials of init_path_tracer)."""
+    tall box and a glossy short box.  Material ids 2.. index `materials` (settings.materials of init_path_tracer)."""
     wv = np.array([[-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0], [-1, -1, 2], [1, -1, 2], [1, 1, 2], [-1, 1, 2]], float)
     grey = np.asarray(_quad(0, 1, 2, 3) + _quad(4, 7, 6, 5) + _quad(3, 2, 6, 7))     # floor, ceiling, back
     left, right = np.asarray(_quad(0, 3, 7, 4)), np.asarray(_quad(1, 5, 6, 2))
@@ -75,9 +75,10 @@ def cornell_box_ext():
     meshes = [mesh_from_vertices(wv, grey), mesh_from_vertices(wv, left), mesh_from_vertices(wv, right), mesh_from_vertices(lv, lf),
               mesh_from_vertices(b1v, b1f), mesh_from_vertices(b2v, b2f)]
     ident = ([0, 0, 0], [0, 0, 0], [1, 1, 1])
-    inst = [(0, *ident, 0), (1, *ident, 2), (2, *ident, 3), (3, *ident, 4), (4, *ident, 5), (5, *ident, 1)]
+    inst = [(0, *ident, 0), (1, *ident, 2), (2, *ident, 3), (3, *ident, 4), (4, *ident, 5), (5, *ident, 6)]
     materials = [{"type": "lambert", "albedo": [0.63, 0.065, 0.05]}, {"type": "lambert", "albedo": [0.14, 0.45, 0.091]},
-                 {"type": "emitter", "emission": [17.0, 12.0, 4.0]}, {"type": "mirror", "albedo": [0.9, 0.9, 0.9]}]
+                 {"type": "emitter", "emission": [17.0, 12.0, 4.0]}, {"type": "mirror", "albedo": [0.9, 0.9, 0.9]},
+                 {"type": "glossy", "albedo": [0.8, 0.7, 0.3], "roughness": 0.35}]
     return {"meshes": meshes, "instances": inst, "camera": {"position": [0.0, -4.6, 1.0], "lookAt": [0.0, 0.0, 1.0], "fov": 20.0},
             "materials": materials}
 
@@ -197,6 +198,20 @@ def instanced_scene(n_side=500, seed=5, grid=10):
     inst.append((1, [10, 10, -1.3], [0, 0, 0], [5, 5, 5], 0))
     return {"meshes": [base, {"file": FLOOR_OBJ}], "instances": inst,
             "camera": {"position": [15, 15, 5], "lookAt": [10, 10, 0], "fov": 60}}
+
+
+def instanced_scene_ext(n_side=500, seed=5, grid=10):
+    """C5 as BASELINE.json words it ("mixed diffuse/specular/glossy materials, 8-bounce"; no reference counterpart):
+    instanced_scene with the instances' materials cycling through the reference's dark grey (1), an orange Lambert (2), a mirror (3)
+    and two glossy metals (4, 5); `settings` carries the material table and the bounce cut (num_bounces advances by 2 per bounce,
+    logic.js:85,137: 8 bounces = maxNb 16)."""
+    desc = instanced_scene(n_side, seed, grid)
+    cycle = [1, 2, 3, 4, 5]
+    desc["instances"] = [(mi, pos, rot, scl, cycle[i % 5] if mi == 0 else mat) for i, (mi, pos, rot, scl, mat) in enumerate(desc["instances"])]
+    desc["materials"] = [{"type": "lambert", "albedo": [0.8, 0.35, 0.05]}, {"type": "mirror", "albedo": [0.9, 0.9, 0.9]},
+                         {"type": "glossy", "albedo": [0.95, 0.75, 0.35], "roughness": 0.15}, {"type": "glossy", "albedo": [0.6, 0.7, 0.9], "roughness": 0.5}]
+    desc["settings"] = {"maxNb": 16, "materials": desc["materials"]}
+    return desc
 
 
 def random_soup(n_tris, seed, extent=4.0, size=0.35):

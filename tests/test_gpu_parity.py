@@ -309,7 +309,8 @@ def test_extensions_closed_forms_and_reset(pta, device):
     s = pta.scenes.populate(pta.init_scene(device), desc); s.build()
     base = {"device": device, "scene": s, "image": {"width": 16, "height": 16}, "camera": desc["camera"]}
     for mats, expect in (([{"type": "emitter", "emission": [3.0, 1.5, 0.25]}], [3.0, 1.5, 0.25]),
-                         ([{"type": "mirror", "albedo": [0.5, 0.25, 1.0]}], [1.0, 0.5, 2.0])):
+                         ([{"type": "mirror", "albedo": [0.5, 0.25, 1.0]}], [1.0, 0.5, 2.0]),
+                         ([{"type": "glossy", "albedo": [0.25, 0.5, 0.125], "roughness": 0.6}], [0.5, 1.0, 0.25])):
         pt = pta.init_path_tracer(dict(base, settings={"samples": 8, "numPaths": 300, "materials": mats}))
         for again in range(2):
             pt.run()
@@ -411,14 +412,14 @@ def test_fast_mode_render(pta, orc, device, built):
     np.testing.assert_allclose(img_e[..., :3], orr.image()[..., :3], rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 def test_every_extend_variant_is_bit_exact(pta, orc, device, built, variant):
     """The extend kernel's variants (workgroup shape, LDS/HBM stack split, dispatch order, tiny scene staged in LDS) never
     change a result: whole path state against the oracle after each of 8 steps, on a scene that fits the LDS stage and on
     one that does not."""
     import ctypes as C
-    name = C.create_string_buffer(96)
-    assert device.lib.pt_extend_variants(device.ctx, variant, name, 96) == 4 and name.value
+    name = C.create_string_buffer(200)
+    assert device.lib.pt_extend_variants(device.ctx, variant, name, 200) == 5 and name.value
     try:
         device.call("pt_set_extend_variant", variant)
         for scene_name, w, h, spp, paths in (("cornell", 64, 36, 8, 3000), ("sphere", 48, 32, 8, 2500)):
@@ -431,7 +432,7 @@ def test_every_extend_variant_is_bit_exact(pta, orc, device, built, variant):
                 assert (gs.n_camera, gs.n_material) == (cs.n_camera, cs.n_material)
                 assert_state_equal(pt, orr, step)
     finally:
-        device.call("pt_set_extend_variant", 3)
+        device.call("pt_set_extend_variant", -1)
 
 
 def test_error_behaviour(pta, device):

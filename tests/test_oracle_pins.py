@@ -301,7 +301,11 @@ def test_extensions_default_off(orc, pta):
 def test_extension_emitter_and_mirror_closed_forms(orc, pta):
     e = [3.0, 1.5, 0.25]
     for mats, expect in (([{"type": "emitter", "emission": e}], e),                         # first hit ends the path: exactly e
-                         ([{"type": "mirror", "albedo": [0.5, 0.25, 1.0]}], [1.0, 0.5, 2.0])):   # one bounce into the sky (2): 2 * albedo
+                         ([{"type": "mirror", "albedo": [0.5, 0.25, 1.0]}], [1.0, 0.5, 2.0]),    # one bounce into the sky (2): 2 * albedo
+                         # glossy: whatever the roughness, the blurred mirror direction stays above the plane: one bounce into the sky
+                         ([{"type": "glossy", "albedo": [0.5, 0.25, 1.0], "roughness": 0.0}], [1.0, 0.5, 2.0]),
+                         ([{"type": "glossy", "albedo": [0.25, 0.5, 0.125], "roughness": 0.6}], [0.5, 1.0, 0.25]),
+                         ([{"type": "glossy", "albedo": [0.5, 0.5, 0.5], "roughness": 7.0}], [1.0, 1.0, 1.0])):  # roughness is clamped to 1
         desc = _plane_scene(pta, 2)
         r = orc.OrcRender(orc.OrcScene(desc), 16, 16, desc["camera"], 8, 300, ext={"materials": mats})
         r.run()

@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--paths", type=int, default=1_000_000)
     args = ap.parse_args()
     pta = importlib.import_module("path-tracer_amd")
-    factory, kwargs, w, h, spp = bench.CONFIGS[args.config]
+    factory, kwargs, w, h, spp, _ = bench.CONFIGS[args.config]
     desc = getattr(pta.scenes, factory)(**kwargs)
     dev = pta.request_device(0)
     scene = pta.scenes.populate(pta.init_scene(dev), desc); scene.build()
@@ -38,8 +38,8 @@ def main():
                                "settings": {"samples": spp, "numPaths": args.paths}})
     for _ in range(args.warm_steps):
         st = pt.step()
-    name = C.create_string_buffer(64)
-    nvar = dev.lib.pt_extend_variants(dev.ctx, 0, name, 64)
+    name = C.create_string_buffer(200)
+    nvar = dev.lib.pt_extend_variants(dev.ctx, 0, name, 200)
     variants = [int(v) for v in args.variants.split(",")] if args.variants else list(range(nvar))
     times = {v: [] for v in variants}
     ref = None
@@ -56,11 +56,11 @@ def main():
     print(f"# {args.config}: {scene.info().n_tris} tris, queue after {args.warm_steps} steps: camera {st.n_camera} material {st.n_material} rays {st.n_rays}")
     rows = []
     for v in variants:
-        dev.lib.pt_extend_variants(dev.ctx, v, name, 64)
+        dev.lib.pt_extend_variants(dev.ctx, v, name, 200)
         t = np.array(times[v])
         rows.append({"variant": v, "name": name.value.decode(), "median_us": round(float(np.median(t)), 2), "min_us": round(float(t.min()), 2),
                      "Mrays_s": round(st.n_rays / np.median(t), 1)})
-        print(f"{v:>3} {rows[-1]['name']:<34} median {rows[-1]['median_us']:>9.2f} us   min {rows[-1]['min_us']:>9.2f} us   {rows[-1]['Mrays_s']:>8.1f} Mrays/s")
+        print(f"{v:>3} {rows[-1]['name'][:60]:<60} median {rows[-1]['median_us']:>9.2f} us   min {rows[-1]['min_us']:>9.2f} us   {rows[-1]['Mrays_s']:>8.1f} Mrays/s")
     print(json.dumps({"config": args.config, "rays": int(st.n_rays), "rows": rows}))
     dev.destroy()
 
