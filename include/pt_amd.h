@@ -180,9 +180,10 @@ int pt_render_run(pt_ctx* ctx, int64_t max_steps, int flags, pt_run_stats* out);
  * render; give every context the same image_dev to accumulate one image).  It cannot upload meshes, build a scene or
  * change the traversal mode.  While it lives src keeps count of it: pt_scene_build, pt_set_traversal_mode and pt_destroy on
  * src return PT_ERR_STATE, and so does pt_render_init on src while a borrower still accumulates into src's own image.
- * pt_render_run_many: pt_render_run over n such contexts at once from one host thread -- their batches of steps are
+ * pt_render_run_many: pt_render_run over n contexts at once from one host thread -- their batches of steps are
  * issued in turn on their own streams, so that one pool's compaction launches run in the tail of another's extend
- * launch.  out: n entries (or NULL).  Every pool is bit-identical to the oracle run with the same share; overlapping
+ * launch.  The contexts may also sit on different GPUs (each with its own scene replica and its own share: the
+ * single-process form of the multi-GPU render, see pt_comm_create).  out: n entries (or NULL).  Every pool is bit-identical to the oracle run with the same share; overlapping
  * pools only change when launches run. */
 int pt_create_sharing_scene(pt_ctx* src, pt_ctx** out);
 int pt_render_run_many(pt_ctx** ctxs, int n, int64_t max_steps, int flags, pt_run_stats* out);
@@ -191,12 +192,33 @@ int pt_render_run_many(pt_ctx** ctxs, int n, int64_t max_steps, int flags, pt_ru
  * rgba: W*H*4 floats (rgb = sum of radiance, a = finished samples; logic.js:146-149). */
 int pt_image_read(pt_ctx* ctx, float* rgba, int64_t n_floats);
 int pt_image_dev_ptr(pt_ctx* ctx, void** dev_ptr);
+/* Adds the partial sums of unfinished pixel tickets to the image (on the ctx's stream, not waited for): what pt_image_read does
+ * before it copies.  For callers that consume the device buffer themselves in the middle of a render. */
+int pt_image_flush(pt_ctx* ctx);
 int pt_image_size(pt_ctx* ctx, int32_t* width, int32_t* height);   /* params.image of the current render */
 /* Parity read-back of one PathState member (path-tracer.js:131-160) by name; vec3f/vec4f members
  * come back as 4 floats per slot.  "pixel_counter" returns one int64. */
 int pt_path_state_read(pt_ctx* ctx, const char* field, void* out, size_t bytes);
 /* stage-2 queues of the last step: which = 0 camera_queue, 1 material_queue. *n_io in: capacity, out: count */
 int pt_queue_read(pt_ctx* ctx, int which, int32_t* out, int64_t* n_io);
+
+/* ---- multi-GPU (NO reference counterpart: the reference is a single-device browser app) ----
+ * Samples are independent, so a render shards with no exchange on the data path: every GPU holds the whole scene and renders
+ * its own pixel-ticket range with its own RNG streams (pt_render_params.slot_base / ticket_begin / ticket_end), into its own
+ * accumulation buffer.  The ONE collective is the sum of those buffers: pt_comm_reduce_image = RCCL ncclReduce(sum, float32,
+ * W*H*4) over xGMI onto rank `root`'s image, in place, ordered behind the renders on the contexts' streams, waited for.
+ * The image is sums of radiance and sample counts (logic.js:146-149), so the sum has the single-GPU image's form.
+ *   pt_comm_create        one process drives several GPUs: ctxs[i] is rank i (one context per GPU; ncclCommInitAll)
+ *   pt_comm_unique_id +   one process per GPU: rank 0 makes the 128-byte id, the host passes it to the other ranks by its own
+ *   pt_comm_create_rank   means (environment, file, torch.distributed store), every rank joins with its context (ncclCommInitRank)
+ * librccl is loaded on first use; without it these return PT_ERR_STATE. */
+typedef struct pt_comm pt_comm;
+#define PT_COMM_ID_BYTES 128
+int  pt_comm_create(pt_ctx** ctxs, int n, pt_comm** out);
+int  pt_comm_unique_id(void* id128);
+int  pt_comm_create_rank(pt_ctx* ctx, const void* id128, int rank, int world, pt_comm** out);
+int  pt_comm_reduce_image(pt_comm* comm, int root);
+void pt_comm_destroy(pt_comm* comm);
 
 /* ---- fast mode (NO reference counterpart, OUTSIDE the bit-exact contract, default off) ----
  * PT_TRAVERSAL_WIDE: inside an object the extend kernel walks a 4-wide collapse of the reference's binary BVH (each inner

@@ -82,6 +82,12 @@ SIGNATURES = {
     "pt_render_run_many": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int, C.POINTER(PtRunStats)]),
     "pt_image_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "pt_image_dev_ptr": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "pt_image_flush": (C.c_int, [C.c_void_p]),
+    "pt_comm_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p)]),
+    "pt_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "pt_comm_create_rank": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "pt_comm_reduce_image": (C.c_int, [C.c_void_p, C.c_int]),
+    "pt_comm_destroy": (None, [C.c_void_p]),
     "pt_path_state_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),
     "pt_queue_read": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int64)]),
     "pt_extend_variants": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]),

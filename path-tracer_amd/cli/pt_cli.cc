@@ -2,7 +2,10 @@
 // (registerMesh x k -> instanceMesh x m -> build -> initPathTracer -> loop { step } -> display) in C++ over the C ABI.
 //
 //   pt_cli [--obj FILE]... [--instance MESH,px,py,pz,rx,ry,rz,sx,sy,sz,MATERIAL]... [--camera px,py,pz,lx,ly,lz,fov]
-//          [--width W] [--height H] [--samples S] [--paths N] [--pools K] [--device D] [--progress K] [--out frame.png|frame.ppm] [--json]
+//          [--width W] [--height H] [--samples S] [--paths N] [--pools K] [--device D] [--gpus G] [--progress K] [--out frame.png|frame.ppm] [--json]
+//          [--material TYPE,r,g,b[,e0,e1,e2]]... [--max-nb N] [--seed S]      extensions (material ids 2, 3, ...; TYPE lambert|emitter|mirror|glossy)
+// --gpus G: the samples are split over GPUs 0..G-1 of this node -- every GPU gets the scene, its own RNG streams and the
+// g-th part of the pixel tickets -- and the accumulation buffers are summed onto GPU 0 by one RCCL reduce (pt_comm_reduce_image).
 //   pt_cli --dump-host FILE px,py,pz,rx,ry,rz,sx,sy,sz      host-side results only (no GPU): parse + matrices + world box as JSON
 //
 // Without --obj the scene is the reference's bundled floor with its main.js:33 instance and main.js:42-46 camera.
@@ -98,7 +101,8 @@ static int dump_host(const std::string& file, const std::string& trs) {
 
 int main(int argc, char** argv) {
     std::vector<std::string> objs, insts; std::string cam, out; bool json = false;
-    int width = 512, height = 512, samples = 16, paths = 0, device = 0, progress = 0, pools = 1;
+    int width = 512, height = 512, samples = 16, paths = 0, device = 0, progress = 0, pools = 1, gpus = 1;
+    pt_render_ext ext; memset(&ext, 0, sizeof ext); bool have_ext = false;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto next = [&]() -> std::string { return i + 1 < argc ? argv[++i] : ""; };
@@ -112,6 +116,20 @@ int main(int argc, char** argv) {
         else if (a == "--paths") paths = atoi(next().c_str());
         else if (a == "--pools") pools = std::max(1, atoi(next().c_str()));
         else if (a == "--device") device = atoi(next().c_str());
+        else if (a == "--gpus") gpus = std::max(1, atoi(next().c_str()));
+        else if (a == "--max-nb") { ext.max_nb = atoi(next().c_str()); have_ext = true; }
+        else if (a == "--seed") { ext.seed = (uint32_t)strtoul(next().c_str(), nullptr, 10); have_ext = true; }
+        else if (a == "--material") {
+            std::string spec = next(); size_t comma = spec.find(',');
+            std::string type = spec.substr(0, comma); std::vector<double> v = comma == std::string::npos ? std::vector<double>{} : csv(spec.substr(comma + 1));
+            v.resize(6, 0.0);
+            if (ext.n_materials >= PT_MAX_EXT_MATERIALS) { fprintf(stderr, "at most %d --material\n", PT_MAX_EXT_MATERIALS); return 2; }
+            pt_material& m = ext.materials[ext.n_materials++];
+            m.type = type == "lambert" ? PT_MAT_LAMBERT : type == "emitter" ? PT_MAT_EMITTER : type == "mirror" ? PT_MAT_MIRROR : type == "glossy" ? PT_MAT_GLOSSY : -1;
+            if (m.type < 0) { fprintf(stderr, "unknown material type %s\n", type.c_str()); return 2; }
+            for (int k = 0; k < 3; k++) { m.albedo[k] = (float)v[k]; m.emission[k] = (float)v[3 + k]; }     // glossy: e0 = roughness
+            have_ext = true;
+        }
         else if (a == "--progress") progress = atoi(next().c_str());
         else if (a == "--out") out = next();
         else if (a == "--json") json = true;
@@ -124,16 +142,23 @@ int main(int argc, char** argv) {
     std::vector<double> c = cam.empty() ? std::vector<double>{15, 15, 5, 10, 10, 0, 60} : csv(cam);                       // main.js:42-46
     c.resize(7, 60.0);
 
-    pt_ctx* ctx = nullptr;
-    CHECK(pt_create(device, &ctx));
+    pt_ctx* ctx = nullptr;                                                        // GPU `device`; with --gpus G also device + 1 .. device + G - 1
+    std::vector<pt_ctx*> gpu_ctx;
     std::vector<int> handles; std::vector<Bounds> bounds;
-    for (const std::string& t : texts) {                                          // registerMesh (scene.js:518)
-        ParsedObj p = parse_obj(t);
-        std::vector<float> tris(p.tris.begin(), p.tris.end());                    // builders.js:164 Float32Array.set
-        float b6[6]; for (int k = 0; k < 3; k++) { b6[k] = (float)p.bounds.mn[k]; b6[3 + k] = (float)p.bounds.mx[k]; }
-        int h = pt_mesh_upload(ctx, tris.data(), p.num_triangles(), b6);
-        if (h < 0) { fprintf(stderr, "pt_mesh_upload failed (%d): %s\n", h, pt_last_error(ctx)); pt_destroy(ctx); return 1; }
-        handles.push_back(h); bounds.push_back(p.bounds);
+    std::vector<ParsedObj> parsed;
+    for (const std::string& t : texts) parsed.push_back(parse_obj(t));
+    for (int g = 0; g < gpus; g++) {
+        pt_ctx* cg = nullptr;
+        { int rc_ = pt_create(device + g, &cg); if (rc_ < 0) { fprintf(stderr, "pt_create(%d) failed (%d): %s\n", device + g, rc_, pt_last_error(nullptr)); return 1; } }
+        if (g == 0) ctx = cg;
+        gpu_ctx.push_back(cg);
+        for (const ParsedObj& p : parsed) {                                       // registerMesh (scene.js:518), once per GPU: the scene is replicated
+            std::vector<float> tris(p.tris.begin(), p.tris.end());                // builders.js:164 Float32Array.set
+            float b6[6]; for (int k = 0; k < 3; k++) { b6[k] = (float)p.bounds.mn[k]; b6[3 + k] = (float)p.bounds.mx[k]; }
+            int h = pt_mesh_upload(cg, tris.data(), p.num_triangles(), b6);
+            if (h < 0) { fprintf(stderr, "pt_mesh_upload failed (%d): %s\n", h, pt_last_error(cg)); return 1; }
+            if (g == 0) { handles.push_back(h); bounds.push_back(p.bounds); }
+        }
     }
     std::vector<pt_instance> inst;
     for (const std::string& s : insts) {                                          // instanceMesh (scene.js:523-529) + scene.js:35-46
@@ -148,7 +173,7 @@ int main(int argc, char** argv) {
         pi.mesh = handles[mesh]; pi.material = (int)v[10];
         inst.push_back(pi);
     }
-    CHECK(pt_scene_build(ctx, inst.data(), (int)inst.size()));
+    for (pt_ctx* cg : gpu_ctx) CHECK(pt_scene_build(cg, inst.data(), (int)inst.size()));
     pt_scene_info si; CHECK(pt_scene_get_info(ctx, &si));
 
     pt_render_params rp; memset(&rp, 0, sizeof rp);
@@ -156,16 +181,26 @@ int main(int argc, char** argv) {
     for (int k = 0; k < 3; k++) { rp.cam_pos[k] = (float)c[k]; rp.cam_look_at[k] = (float)c[3 + k]; }
     // --pools K > 1 (no reference counterpart, pt_amd.h "several path pools on one GPU"): K contexts that borrow the scene,
     // pool k with its own RNG streams and the k-th part of the pixel tickets, all adding into pool 0's image
-    std::vector<pt_ctx*> pool{ctx};
+    // --gpus G: the same split one level up -- GPU g takes the g-th part of the tickets (and its pools split that part)
+    std::vector<pt_ctx*> pool;                                                    // pool[g * pools + k]
     const long long per_pool = paths > 0 ? paths : 1000000, total = ((long long)width * height * samples + 7) / 8;   // logic.js:177
-    for (int k = 0; k < pools; k++) {
-        if (k > 0) { pt_ctx* c2 = nullptr; CHECK(pt_create_sharing_scene(ctx, &c2)); pool.push_back(c2); }
-        if (pools > 1) {
-            rp.num_paths = (int32_t)per_pool; rp.slot_base = k * per_pool; rp.ticket_begin = total * k / pools; rp.ticket_end = total * (k + 1) / pools;
-            if (k > 0) CHECK(pt_image_dev_ptr(ctx, &rp.image_dev));
+    const int shares = gpus * pools;
+    for (int g = 0; g < gpus; g++)
+        for (int k = 0; k < pools; k++) {
+            pt_ctx* pc = gpu_ctx[g];
+            if (k > 0) CHECK(pt_create_sharing_scene(gpu_ctx[g], &pc));
+            pool.push_back(pc);
+            const int sh = g * pools + k;
+            rp.image_dev = nullptr;
+            if (shares > 1) {
+                rp.num_paths = (int32_t)per_pool; rp.slot_base = sh * per_pool; rp.ticket_begin = total * sh / shares; rp.ticket_end = total * (sh + 1) / shares;
+                if (k > 0) CHECK(pt_image_dev_ptr(gpu_ctx[g], &rp.image_dev));
+            }
+            CHECK(pt_render_init(pc, &rp));
+            if (have_ext) CHECK(pt_render_set_extensions(pc, &ext));
         }
-        CHECK(pt_render_init(pool[k], &rp));
-    }
+    pt_comm* comm = nullptr;
+    if (gpus > 1 || getenv("PT_CLI_FORCE_COMM")) CHECK(pt_comm_create(gpu_ctx.data(), gpus, &comm));   // one rank per GPU
 
     std::vector<uint8_t> rgba((size_t)width * height * 4);
     long long steps = 0, rays = 0; int frames = 0;
@@ -174,6 +209,7 @@ int main(int argc, char** argv) {
         for (pt_ctx* pc : pool) { pt_step_stats s1; CHECK(pt_render_step(pc, &s1)); st.n_rays += s1.n_rays; st.n_camera += s1.n_camera; st.n_material += s1.n_material; }
         steps++; rays += st.n_rays;
         bool done = st.n_camera + st.n_material == 0;
+        if (done && comm) CHECK(pt_comm_reduce_image(comm, 0));                   // sum of the GPUs' accumulation buffers onto GPU 0 (RCCL)
         if (!out.empty() && (done || (progress > 0 && steps % progress == 0))) {
             CHECK(pt_tonemap_rgba8(ctx, nullptr, 0, 0, rgba.data()));
             if (!write_image(out, rgba.data(), width, height)) { fprintf(stderr, "cannot write %s\n", out.c_str()); pt_destroy(ctx); return 2; }
@@ -182,13 +218,16 @@ int main(int argc, char** argv) {
         if (done) break;
     }
     std::vector<float> img((size_t)width * height * 4);
-    for (int k = pools - 1; k >= 0; k--) CHECK(pt_image_read(pool[k], img.data(), (int64_t)img.size()));   // each read adds that pool's open tickets
+    for (int k = pools - 1; k >= 0; k--) CHECK(pt_image_read(pool[k], img.data(), (int64_t)img.size()));   // GPU 0's pools; each read adds that pool's open tickets
     double wsum = 0, rsum = 0; for (size_t i = 0; i < (size_t)width * height; i++) { wsum += img[4 * i + 3]; rsum += img[4 * i]; }
     if (json) printf("{\"width\": %d, \"height\": %d, \"samples\": %d, \"steps\": %lld, \"rays\": %lld, \"sampleCount\": %.17g, \"radianceSum\": %.17g, "
-                     "\"nTris\": %lld, \"nObjects\": %d, \"frames\": %d}\n", width, height, samples, steps, rays, wsum, rsum, (long long)si.n_tris, si.n_objects, frames);
+                     "\"nTris\": %lld, \"nObjects\": %d, \"frames\": %d, \"gpus\": %d, \"reduced\": %s}\n", width, height, samples, steps, rays, wsum, rsum, (long long)si.n_tris, si.n_objects, frames, gpus, comm ? "true" : "false");
     else printf("%dx%d, %d spp: %lld steps, %lld rays, %lld triangles in %d instances%s%s\n", width, height, samples, steps, rays,
                 (long long)si.n_tris, si.n_objects, out.empty() ? "" : " -> ", out.c_str());
-    for (int k = pools - 1; k > 0; k--) pt_destroy(pool[k]);
-    pt_destroy(ctx);
+    if (comm) pt_comm_destroy(comm);
+    for (int g = gpus - 1; g >= 0; g--) {
+        for (int k = pools - 1; k > 0; k--) pt_destroy(pool[g * pools + k]);      // the borrowers first
+        pt_destroy(gpu_ctx[g]);
+    }
     return 0;
 }

@@ -281,6 +281,11 @@ int write_header(pt_ctx* c) {
 
 }  // namespace
 
+// for pt_comm.hip (struct pt_ctx is private to this file)
+int pt_ctx_device(const pt_ctx* c) { return c->device; }
+hipStream_t pt_ctx_stream(const pt_ctx* c) { return c->stream; }
+int pt_ctx_fail(pt_ctx* c, int code, const std::string& msg) { return fail(c, code, msg); }
+
 extern "C" {
 
 int pt_create(int device_id, pt_ctx** out) {
@@ -647,6 +652,7 @@ struct RunState { pt_ctx* c; double extend_ms = 0.0; int64_t launches = 0, issue
 const int POLL = 8;   // steps between looks at the queue sizes (the reference never looks: main.js:61-72)
 int run_issue(RunState& rs, int64_t batch, int64_t max_steps, bool timed, int count) {
     pt_ctx* c = rs.c;
+    HIPOK(c, hipSetDevice(c->device));        // the contexts may sit on different GPUs (one host thread drives them all)
     int p = (int)(batch & 1); rs.had_timed[p] = false;
     for (int k = 0; k < POLL && rs.issued < max_steps; k++, rs.issued++) {
         bool t = timed && (batch & 1) == 0 && k == (int)((batch >> 1) % POLL);   // one launch in 2 * POLL
@@ -661,6 +667,7 @@ int run_issue(RunState& rs, int64_t batch, int64_t max_steps, bool timed, int co
 int run_collect(RunState& rs, int64_t batch) {
     pt_ctx* c = rs.c;
     int p = (int)(batch & 1);
+    HIPOK(c, hipSetDevice(c->device));
     HIPOK(c, hipEventSynchronize(c->events[3 * p + 2]));
     if (rs.had_timed[p]) { float ms = 0; HIPOK(c, hipEventElapsedTime(&ms, c->events[3 * p], c->events[3 * p + 1])); rs.extend_ms += ms; rs.launches++; }
     return PT_OK;
@@ -672,17 +679,17 @@ int pt_render_run_many(pt_ctx** ctxs, int n, int64_t max_steps, int flags, pt_ru
     for (int i = 0; i < n; i++) {
         if (!ctxs[i]) return PT_ERR_ARG;
         if (!ctxs[i]->render_ready) return fail(ctxs[i], PT_ERR_STATE, "pt_render_run: pt_render_init has not been called");
-        if (ctxs[i]->device != ctxs[0]->device) return fail(ctxs[i], PT_ERR_ARG, "pt_render_run_many: the contexts are on different devices");
         for (int k = 0; k < i; k++) if (ctxs[k] == ctxs[i]) return fail(ctxs[i], PT_ERR_ARG, "pt_render_run_many: the same context twice");
     }
-    HIPOK(ctxs[0], hipSetDevice(ctxs[0]->device));
     bool timed = (flags & PT_RUN_TIME_EXTEND) != 0; int count = (flags & PT_RUN_COUNT_BYTES) ? 1 : 0;
     if (max_steps <= 0) max_steps = INT64_MAX;
     std::vector<RunState> rs((size_t)n);
     int r;
     for (int i = 0; i < n; i++) {
         pt_ctx* c = rs[i].c = ctxs[i];
-        c->overlapped = n > 1;
+        c->overlapped = false;
+        for (int k = 0; k < n; k++) if (k != i && ctxs[k]->device == c->device) c->overlapped = true;   // another pool on this GPU
+        HIPOK(c, hipSetDevice(c->device));
         if (c->events.empty()) {   // per batch parity: [0,1] bracket a timed extend launch, [2] marks "header copy landed"
             c->events.resize(6);
             for (hipEvent_t& e : c->events) HIPOK(c, hipEventCreate(&e));
@@ -712,6 +719,7 @@ int pt_render_run_many(pt_ctx** ctxs, int n, int64_t max_steps, int flags, pt_ru
         pt_ctx* c = ctxs[i];
         if (rs[i].last & 1) c->h_hdr[0] = c->h_hdr[1];             // the final header lives in h_hdr[0] for the code below
         if (c->h_hdr->first_empty_step < 0) {   // stopped by max_steps: bring the image up to date for the caller
+            HIPOK(c, hipSetDevice(c->device));
             ptk_flush_tickets(c->ps, c->rc.num_paths, c->d_image, c->stream);
             HIPOK(c, hipStreamSynchronize(c->stream));
         }
@@ -741,6 +749,15 @@ int pt_image_read(pt_ctx* c, float* rgba, int64_t n_floats) {
     HIPOK(c, hipSetDevice(c->device));
     ptk_flush_tickets(c->ps, c->rc.num_paths, c->d_image, c->stream);
     return read_back(c, rgba, c->d_image, (size_t)n_floats * 4);
+}
+
+int pt_image_flush(pt_ctx* c) {
+    if (!c) return PT_ERR_ARG;
+    if (!c->render_ready) return fail(c, PT_ERR_STATE, "pt_image_flush: pt_render_init has not been called");
+    HIPOK(c, hipSetDevice(c->device));
+    ptk_flush_tickets(c->ps, c->rc.num_paths, c->d_image, c->stream);
+    HIPOK(c, hipGetLastError());
+    return PT_OK;
 }
 
 int pt_image_dev_ptr(pt_ctx* c, void** dev_ptr) {

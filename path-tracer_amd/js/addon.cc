@@ -277,12 +277,44 @@ static napi_value Tonemap(napi_env env, napi_callback_info info) {
     return nullptr;
 }
 
+// commCreate([ctx, ...]) -> comm handle: one rank per GPU, in array order                       [pt_comm_create]
+static void finalize_comm(napi_env, void* data, void*) { pt_comm** h = (pt_comm**)data; if (*h) pt_comm_destroy(*h); delete h; }
+static napi_value CommCreate(napi_env env, napi_callback_info info) {
+    napi_value a[1]; if (!get_args(env, info, 1, a)) return nullptr;
+    uint32_t n = 0; napi_get_array_length(env, a[0], &n);
+    if (n < 1 || n > 64) { napi_throw_type_error(env, nullptr, "expected an array of 1..64 contexts"); return nullptr; }
+    pt_ctx* cs[64];
+    for (uint32_t i = 0; i < n; i++) { napi_value e; napi_get_element(env, a[0], i, &e); cs[i] = ctx_of(env, e); if (!cs[i]) return nullptr; }
+    pt_comm* comm = nullptr; int rc = pt_comm_create(cs, (int)n, &comm);
+    if (rc < 0) return throw_pt(env, cs[0], "pt_comm_create", rc);
+    pt_comm** h = new pt_comm*(comm);
+    napi_value ext; NAPI_OK(napi_create_external(env, h, finalize_comm, nullptr, &ext));
+    return ext;
+}
+// commReduceImage(comm, root): sum of the ranks' accumulation buffers onto rank root's (RCCL)  [pt_comm_reduce_image]
+static napi_value CommReduceImage(napi_env env, napi_callback_info info) {
+    napi_value a[2]; if (!get_args(env, info, 2, a)) return nullptr;
+    void* p = nullptr;
+    if (napi_get_value_external(env, a[0], &p) != napi_ok || !p || !*(pt_comm**)p) { napi_throw_type_error(env, nullptr, "expected a live comm handle"); return nullptr; }
+    int rc = pt_comm_reduce_image(*(pt_comm**)p, (int)i64(env, a[1]));
+    if (rc < 0) { napi_throw_error(env, nullptr, ("pt_comm_reduce_image failed (" + std::to_string(rc) + ")").c_str()); return nullptr; }
+    return nullptr;
+}
+// commDestroy(comm)                                                                            [pt_comm_destroy]
+static napi_value CommDestroy(napi_env env, napi_callback_info info) {
+    napi_value a[1]; if (!get_args(env, info, 1, a)) return nullptr;
+    void* p = nullptr; napi_get_value_external(env, a[0], &p);
+    if (p && *(pt_comm**)p) { pt_comm_destroy(*(pt_comm**)p); *(pt_comm**)p = nullptr; }
+    return nullptr;
+}
+
 static napi_value Init(napi_env env, napi_value exports) {
     struct { const char* name; napi_callback fn; } fns[] = {
         {"create", Create}, {"createSharingScene", CreateSharingScene}, {"renderRunMany", RenderRunMany}, {"destroy", Destroy}, {"meshUpload", MeshUpload}, {"sceneBuild", SceneBuild}, {"sceneInfo", SceneInfo},
         {"readBuffer", ReadBuffer}, {"traceRays", TraceRays}, {"renderInit", RenderInit}, {"renderReset", RenderReset},
         {"renderSetExtensions", RenderSetExtensions},
-        {"renderStep", RenderStep}, {"renderRun", RenderRun}, {"imageRead", ImageRead}, {"tonemap", Tonemap}};
+        {"renderStep", RenderStep}, {"renderRun", RenderRun}, {"imageRead", ImageRead}, {"tonemap", Tonemap},
+        {"commCreate", CommCreate}, {"commReduceImage", CommReduceImage}, {"commDestroy", CommDestroy}};
     for (auto& f : fns) {
         napi_value v; napi_create_function(env, f.name, NAPI_AUTO_LENGTH, f.fn, nullptr, &v);
         napi_set_named_property(env, exports, f.name, v);

@@ -3,7 +3,9 @@
 // (registerMesh x k -> instanceMesh x m -> await build() -> initPathTracer -> initDisplay -> loop { await step(); draw() }),
 // no browser.  The reference's demo meshes (cow / bunny / buddha) are not distributed with it, so the demo scene is
 // the floor it does bundle under a lattice of generated boxes standing in for the 100 instanced meshes (main.js:25-33).
-//   node main.js [--width W] [--height H] [--samples S] [--paths N] [--pools K] [--grid G] [--out frame.png] [--progress K] [--json] [--ext]
+//   node main.js [--width W] [--height H] [--samples S] [--paths N] [--pools K] [--gpus G] [--grid G] [--out frame.png] [--progress K] [--json] [--ext]
+// --gpus G splits the samples over GPUs 0..G-1 (each builds the scene and renders its part of the pixel tickets with its own RNG
+// streams); the accumulation buffers are summed onto GPU 0 by one RCCL reduce before the final draw (pt-host.js initMultiGpu).
 // --progress K redraws (rewrites the PNG) every K steps, the headless form of the reference's draw-every-frame loop.
 // --ext switches the extensions on (not in the reference): box i gets material 1 + i % 4, i.e. the reference's dark grey,
 // an orange Lambert, a mirror and a warm emitter; bounce cut at nb > 8; seed 3.
@@ -24,27 +26,34 @@ function arg(name, dflt) {
 
 async function main() {
     const width = +arg("width", 512), height = +arg("height", 512), samples = +arg("samples", 16), grid = +arg("grid", 10)
-    const device = pt.requestDevice(+arg("device", 0))
-    const scene = pt.initScene(device)
-    const t0 = Date.now()
-
-    const box = scene.registerMesh({ file: BOX })
-    const floor = scene.registerMesh({ file: FLOOR })
-    let lcg = 12345                                  // seeded stand-in for Math.random() (main.js:28) so runs are repeatable
-    for (let i = 0; i < grid * grid; i++) {
-        lcg = (Math.imul(lcg, 1664525) + 1013904223) >>> 0
-        scene.instanceMesh(box, [(i % grid) * 2, Math.floor(i / grid) * 2, -1.3], [0, 0, lcg / 4294967296 * Math.PI * 2.], [1, 1, 1],
-                           arg("ext", false) ? 1 + i % 4 : 1)
+    const gpus = Math.max(1, +arg("gpus", 1)), t0 = Date.now()
+    const settings = Object.assign({ samples, numPaths: +arg("paths", 0), pools: +arg("pools", 1) }, arg("ext", false) ? EXT : {})
+    const camera = { lookAt: [10, 10, 0], position: [15, 15, 5], fov: 60 }       // main.js:42-46
+    const devices = [], scenes = [], tracers = []
+    for (let g = 0; g < gpus; g++) {                 // one device, one scene replica and one tracer per GPU (G = 1: the reference's sequence)
+        const device = pt.requestDevice(+arg("device", 0) + g)
+        const scene = pt.initScene(device)
+        const box = scene.registerMesh({ file: BOX })
+        const floor = scene.registerMesh({ file: FLOOR })
+        let lcg = 12345                              // seeded stand-in for Math.random() (main.js:28) so runs are repeatable
+        for (let i = 0; i < grid * grid; i++) {
+            lcg = (Math.imul(lcg, 1664525) + 1013904223) >>> 0
+            scene.instanceMesh(box, [(i % grid) * 2, Math.floor(i / grid) * 2, -1.3], [0, 0, lcg / 4294967296 * Math.PI * 2.], [1, 1, 1],
+                               arg("ext", false) ? 1 + i % 4 : 1)
+        }
+        scene.instanceMesh(floor, [10, 10, -1.3], [0, 0, 0], [5, 5, 5], 0)
+        await scene.build()
+        devices.push(device); scenes.push(scene)
+        tracers.push(pt.initPathTracer({ device, scene, image: { width, height }, camera,
+                                         settings: gpus > 1 ? pt.shareOf(g, gpus, { width, height }, settings) : settings }))
     }
-    scene.instanceMesh(floor, [10, 10, -1.3], [0, 0, 0], [5, 5, 5], 0)
-    await scene.build()
-
-    const tracer = pt.initPathTracer({
-        device, scene,
-        image: { width, height },
-        camera: { lookAt: [10, 10, 0], position: [15, 15, 5], fov: 60 },     // main.js:42-46
-        settings: Object.assign({ samples, numPaths: +arg("paths", 0), pools: +arg("pools", 1) }, arg("ext", false) ? EXT : {}),
-    })
+    const device = devices[0], scene = scenes[0]
+    const multi = gpus > 1 || arg("force-comm", false) ? pt.initMultiGpu(devices) : null
+    const tracer = gpus === 1 ? tracers[0] : {       // every GPU takes the step; the queue sizes add up
+        async step() { const r = []; for (const t of tracers) r.push(await t.step()); const sum = f => r.reduce((a, x) => a + x[f], 0)
+                       return { camera: sum("camera"), material: sum("material"), rays: sum("rays") } },
+        getImageBuffer: tracers[0].getImageBuffer, readImage: () => tracers[0].readImage(), destroy() { tracers.forEach(t => t.destroy()) },
+    }
     const display = pt.initDisplay({ device, canvas: arg("out", null), image: { buffer: tracer.getImageBuffer(), width, height } })
 
     // the reference's frame loop never learns that the render finished (main.js:61-72); headless, it stops on empty queues
@@ -56,16 +65,18 @@ async function main() {
         if (+arg("progress", 0) > 0 && steps % +arg("progress", 0) === 0) { display.draw(); frames++ }     // main.js:69
         if (st.camera + st.material === 0) break
     }
+    if (multi) multi.reduceImage(0)                  // the GPUs' accumulation buffers, summed onto GPU 0 (RCCL over xGMI)
     const t2 = Date.now()
     const rgba = display.draw()
     const img = tracer.readImage()
     let wsum = 0, rsum = 0
     for (let i = 0; i < width * height; i++) { wsum += img[4 * i + 3]; rsum += img[4 * i] }
-    const report = { width, height, samples, steps, rays, frames: frames + 1, buildMs: t1 - t0, renderMs: t2 - t1, sampleCount: wsum, radianceSum: rsum,
+    const report = { width, height, samples, steps, rays, gpus, reduced: !!multi, frames: frames + 1, buildMs: t1 - t0, renderMs: t2 - t1, sampleCount: wsum, radianceSum: rsum,
                      firstPixel: Array.from(rgba.slice(0, 4)), info: scene.kernels.getSceneBindGroupInfo() }
     console.log(arg("json", false) ? JSON.stringify(report) : report)
+    if (multi) multi.destroy()
     tracer.destroy()                 // pool contexts borrow the device's scene: they go first
-    device.destroy()
+    devices.forEach(d => d.destroy())
 }
 
 main().catch(e => { console.error(e.message || e); process.exit(1) })

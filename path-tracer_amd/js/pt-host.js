@@ -201,6 +201,22 @@ function initPooledPathTracer(params) {
     return { step, run, readImage, pools, destroy, getImageBuffer: pools[0].getImageBuffer, reset: () => pools.forEach(p => p.reset()) }
 }
 
+// ---- several GPUs of one node (SURVEY 8e; no reference counterpart) ---------------------------------------------------
+// The samples are split: GPU g of G gets the whole scene (build it once per device), the g-th part of the pixel tickets and
+// its own RNG streams -- shareOf(g, G, image, settings) gives the settings for its initPathTracer -- and renders into its own
+// accumulation buffer.  initMultiGpu(devices).reduceImage(root) then adds the buffers onto devices[root]'s with one RCCL
+// sum-reduce over xGMI (pt_comm_reduce_image); that image is the single-GPU image in form (sums of radiance and sample counts).
+function shareOf(g, G, image, settings) {
+    const total = Math.ceil(image.width * image.height * settings.samples / 8)                   // logic.js:177
+    const pools = settings.pools || 1, numPaths = settings.numPaths || 1000000
+    return Object.assign({}, settings, { numPaths, slotBase: g * pools * numPaths,
+        ticketBegin: Math.floor(total * g / G), ticketEnd: Math.floor(total * (g + 1) / G) })
+}
+function initMultiGpu(devices) {
+    const comm = addon().commCreate(devices.map(d => d.ctx))                                      // rank i = devices[i]
+    return { reduceImage(root = 0) { addon().commReduceImage(comm, root) }, destroy() { addon().commDestroy(comm) } }
+}
+
 // ---- initDisplay (display.js): the canvas is a PNG (or raw RGBA8) ------------------------------------------------
 function initDisplay(params) {
     const { width, height } = params.image
@@ -269,4 +285,4 @@ function encodePNG(rgba, w, h) {
     return Buffer.concat([Buffer.from([137, 80, 78, 71, 13, 10, 26, 10]), chunk("IHDR", ihdr), chunk("IDAT", zlib.deflateSync(raw)), chunk("IEND", Buffer.alloc(0))])
 }
 
-module.exports = { requestDevice, initScene, initPathTracer, initDisplay, initDebugView, parseObj, computeTransformMatrices, getTransformedBoundingBox, encodePNG }
+module.exports = { requestDevice, initScene, initPathTracer, initDisplay, initDebugView, initMultiGpu, shareOf, parseObj, computeTransformMatrices, getTransformedBoundingBox, encodePNG }

@@ -73,17 +73,21 @@ def read_png(path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("pools", [1, 2])
-def test_cli_render_equals_python_host_render(cli, pta, device, tmp_path, pools):
+@pytest.mark.parametrize("pools,comm", [(1, False), (2, False), (2, True)])
+def test_cli_render_equals_python_host_render(cli, pta, device, tmp_path, pools, comm):
     """pt_cli (C++ host -> C ABI) renders the reference's floor scene (main.js:33,42-46); the Python host renders the same:
     identical step / ray / sample counts; radiance to the float-add-order tolerance (--progress draws mid-render, which
-    adds the unfinished tickets' partial sums early and so reorders the adds), PNG pixels within one 8-bit step."""
+    adds the unfinished tickets' partial sums early and so reorders the adds), PNG pixels within one 8-bit step.
+    comm: the multi-GPU path at world size 1 (--gpus 1 with the communicator forced): pt_comm_create + one RCCL reduce of the
+    accumulation buffer onto rank 0, which must leave the frame as it was."""
     w, h, spp, paths = 64, 48, 8, 3000
     out = tmp_path / "frame.png"
     r = subprocess.run([cli, "--width", str(w), "--height", str(h), "--samples", str(spp), "--paths", str(paths), "--pools", str(pools), "--json",
-                        "--progress", "3", "--out", str(out)], capture_output=True, text=True, timeout=240)
+                        "--progress", "3", "--out", str(out), "--gpus", "1"], capture_output=True, text=True, timeout=240,
+                       env=dict(os.environ, PT_CLI_FORCE_COMM="1") if comm else None)
     assert r.returncode == 0, r.stdout + r.stderr
     rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rep["gpus"] == 1 and rep["reduced"] == comm
     desc = pta.scenes.floor_scene()
     s = pta.scenes.populate(pta.init_scene(device), desc); s.build()
     pt = pta.init_path_tracer({"device": device, "scene": s, "image": {"width": w, "height": h}, "camera": desc["camera"],

@@ -567,6 +567,43 @@ def test_staged_scene_stack_bound(pta, orc, device, built):
         dev2.destroy()
 
 
+def test_rccl_reduce_at_world_size_one(pta, device, built):
+    """SURVEY 8e in the library: pt_comm_create over this box's one GPU (and the process-per-GPU form with a unique id), one RCCL
+    sum-reduce of the accumulation buffer onto rank 0: the frame must come through untouched, also in the middle of a render
+    (the reduce first adds the unfinished tickets' partial sums, like pt_image_read).  Two contexts on one GPU are refused."""
+    desc, s, o = built("cornell")
+    w, h, spp, paths = 64, 36, 16, 3000
+    pt = pta.init_path_tracer({"device": device, "scene": s, "image": {"width": w, "height": h}, "camera": desc["camera"],
+                               "settings": {"samples": spp, "numPaths": paths}})
+    pt.run(max_steps=6)
+    comm = pta.multigpu.LibComm([device])
+    try:
+        comm.reduce_image(0)
+        mid = pt.read_image().copy()
+        assert 0 < mid[..., 3].sum() < w * h * spp
+        pt.run()
+        before = pt.read_image().copy()
+        comm.reduce_image(0)
+        np.testing.assert_array_equal(pt.read_image().view(np.uint32), before.view(np.uint32))
+        np.testing.assert_array_equal(before[..., 3], np.full((h, w), spp, np.float32))
+        with pytest.raises(pta.capi.PtError, match="bad argument"):
+            comm.reduce_image(1)
+    finally:
+        comm.destroy()
+    c2 = pta.multigpu.LibComm([device], id128=pta.multigpu.LibComm.unique_id(), rank=0, world=1)
+    try:
+        c2.reduce_image(0)
+        np.testing.assert_array_equal(pt.read_image().view(np.uint32), before.view(np.uint32))
+    finally:
+        c2.destroy()
+    dev2 = pta.request_device(0)
+    try:
+        with pytest.raises(pta.capi.PtError, match="one communicator rank per GPU"):
+            pta.multigpu.LibComm([device, dev2])
+    finally:
+        dev2.destroy()
+
+
 def test_pools_on_one_gpu(pta, orc, device, built):
     """settings.pools = 3: three path pools that borrow one scene and add into one image, driven together by
     pt_render_run_many.  Every pool traces exactly the rays of the oracle's run of the same share (its own slot base and

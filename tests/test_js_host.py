@@ -52,16 +52,18 @@ EXT = {"maxNb": 8, "seed": 3, "materials": [{"type": "lambert", "albedo": [0.8, 
 
 @needs_node
 @pytest.mark.gpu
-@pytest.mark.parametrize("ext,pools", [(False, 1), (True, 1), (False, 2)])
-def test_node_render_equals_python_host_render(pta, device, ext, pools):
+@pytest.mark.parametrize("ext,pools,comm", [(False, 1, False), (True, 1, False), (False, 2, False), (False, 2, True)])
+def test_node_render_equals_python_host_render(pta, device, ext, pools, comm):
     """main.js (JS host -> N-API -> C ABI) and the Python host drive the same library: identical frames, with the
     reference's rules, with the extensions (materials, bounce cut, seed) switched on, and with two path pools."""
     w, h, spp, paths, grid = 64, 48, 8, 3000, 3
     r = subprocess.run([NODE, "main.js", "--width", str(w), "--height", str(h), "--samples", str(spp), "--paths", str(paths),
-                        "--pools", str(pools), "--grid", str(grid), "--json", "--out", "/tmp/node_frame.png"] + (["--ext"] if ext else []),
+                        "--pools", str(pools), "--grid", str(grid), "--json", "--out", "/tmp/node_frame.png"] + (["--ext"] if ext else []) +
+                       (["--gpus", "1", "--force-comm"] if comm else []),     # the multi-GPU path at world size 1: one RCCL reduce onto rank 0
                        cwd=JS, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout + r.stderr
     rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rep["gpus"] == 1 and rep["reduced"] == comm
     scene = pta.init_scene(device)
     box = scene.register_mesh({"file": BOX}); floor = scene.register_mesh({"file": pta.scenes.FLOOR_OBJ})
     lcg = 12345
