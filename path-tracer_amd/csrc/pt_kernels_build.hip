@@ -4,7 +4,7 @@
 //   boxes + 30-bit Morton keys -> stable key/index sort (rocPRIM, pt_sort.hip) -> Karras radix
 //   tree (parent links carry the child's side) -> bottom-up refit -> gather triangles -> pack.
 // All of it is HBM-streaming integer/f32 work; no LDS tiling or MFMA applies.  The refit is the
-// only inter-workgroup hand-off and uses agent-scope release/acquire around one arrival counter.
+// only inter-workgroup hand-off: device-scope atomics on both sides of one arrival counter.
 #include "pt_internal.h"
 #include "pt_math.cuh"
 
@@ -93,13 +93,21 @@ __global__ __launch_bounds__(PT_BLOCK) void k_radix_tree(const uint32_t* __restr
     parents[right_slot] = (i << 1) | 1;
 }
 
-// bvh-up-pass.js:199-280.  One thread per leaf climbs the tree; the second child to arrive at a node
-// merges both boxes and continues.  Differences from the reference kernel, none visible in the output
-// of its canonical (serial) execution: the child's slot is its Karras side, not its arrival rank; the
-// first arriver publishes its slot with an agent-scope release before the counter, the second acquires
-// after it, so there is no "is the other half still zero" spin (bvh-up-pass.js:266-268).
+// bvh-up-pass.js:199-280.  One thread per leaf climbs the tree; the second child to arrive at a node merges both boxes and
+// continues.  Differences from the reference kernel, none visible in the output of its canonical (serial) execution: the child's
+// slot is its Karras side, not its arrival rank, and there is no "is the other half still zero" spin (bvh-up-pass.js:266-268).
+// The hand-off between the two arrivers crosses CUs and XCDs, whose L1s and L2s are not coherent with each other.  It is made with
+// device-scope atomics on BOTH sides: a child's 32-byte slot is written by four atomic exchanges (3 x 8 B + 4 B; the fourth word of
+// the left slot's last pair is the arrival counter f_1, bvh-up-pass.js:230, and is never part of an exchange), the wave waits for
+// them (vmcnt), then bumps the counter; the second arriver reads the sibling's slot by atomic adds of a run-time zero.  Atomics are
+// performed at the memory side, so no cache can serve an old value, and nothing is read through a cache inside the launch.
+// (The first version did it with plain stores between two __threadfence(): an L2 write-back and an L1 invalidate per level and
+// thread -- 71.6 ms of the 75 ms the 10 M-triangle build took, profiles/r02_build_trace_grid_before.txt.)
+__device__ __forceinline__ unsigned long long pack2(float a, float b) {
+    return (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
+}
 __global__ __launch_bounds__(PT_BLOCK) void k_up_pass(const int32_t* __restrict__ idx, const float4* __restrict__ aabb,
-                                                      const int32_t* __restrict__ parents, int n, float4* nodes) {
+                                                      const int32_t* __restrict__ parents, int n, float4* nodes, unsigned long long zero) {
     int t = blockIdx.x * PT_BLOCK + threadIdx.x;
     if (t >= n) return;
     int src = idx[t];
@@ -112,17 +120,22 @@ __global__ __launch_bounds__(PT_BLOCK) void k_up_pass(const int32_t* __restrict_
     int w_idx = -(t + 1);
     int link  = parents[(int64_t)n + t];
     for (int level = 0; level < 64; level++) {   // tree depth <= 62 (32 key bits + 30 index bits)
-        int    p = link >> 1, side = link & 1;
-        float* nd = (float*)(nodes + 4 * (int64_t)p);
-        float* slot = nd + 8 * side;
-        slot[0] = mn.x; slot[1] = mn.y; slot[2] = mn.z; ((int*)slot)[3] = w_idx;
-        slot[4] = mx.x; slot[5] = mx.y; slot[6] = mx.z;
-        __threadfence();                                   // release my slot (agent scope)
+        int p = link >> 1, side = link & 1;
+        unsigned long long* nd = (unsigned long long*)(nodes + 4 * (int64_t)p);
+        unsigned long long* slot = nd + 4 * side;
+        atomicExch(slot + 0, pack2(mn.x, mn.y));
+        atomicExch(slot + 1, pack2(mn.z, __int_as_float(w_idx)));
+        atomicExch(slot + 2, pack2(mx.x, mx.y));
+        atomicExch((unsigned*)(slot + 3), __float_as_uint(mx.z));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my slot is in memory before my arrival counts
         int arrived = atomicAdd((int*)nd + 7, 1);          // f_1 doubles as the arrival counter (:230)
         if (arrived == 0) return;                          // first arrival stops (:242)
-        __threadfence();                                   // acquire the sibling's slot
-        const float* sib = nd + 8 * (side ^ 1);
-        f3 smn = F3(sib[0], sib[1], sib[2]), smx = F3(sib[4], sib[5], sib[6]);
+        const unsigned long long* sib = nd + 4 * (side ^ 1);
+        unsigned long long s0 = atomicAdd((unsigned long long*)sib + 0, zero), s1 = atomicAdd((unsigned long long*)sib + 1, zero),
+                           s2 = atomicAdd((unsigned long long*)sib + 2, zero);
+        unsigned s3 = atomicAdd((unsigned*)(sib + 3), (unsigned)zero);
+        f3 smn = F3(__uint_as_float((unsigned)s0), __uint_as_float((unsigned)(s0 >> 32)), __uint_as_float((unsigned)s1));
+        f3 smx = F3(__uint_as_float((unsigned)s2), __uint_as_float((unsigned)(s2 >> 32)), __uint_as_float(s3));
         mn = min3(mn, smn); mx = max3(mx, smx);            // :270-271
         if (p == 0) return;                                // merged into the root (:218 w_idx == 0)
         w_idx = p;
@@ -188,7 +201,7 @@ void ptk_radix_tree(const uint32_t* keys, int64_t n, int32_t* parents, hipStream
     hipLaunchKernelGGL(k_radix_tree, grid_for(n - 1), dim3(PT_BLOCK), 0, s, keys, (int)n, parents);
 }
 void ptk_up_pass(const int32_t* idx, const float4* aabb, const int32_t* parents, int64_t n, float4* nodes, hipStream_t s) {
-    hipLaunchKernelGGL(k_up_pass, grid_for(n), dim3(PT_BLOCK), 0, s, idx, aabb, parents, (int)n, nodes);
+    hipLaunchKernelGGL(k_up_pass, grid_for(n), dim3(PT_BLOCK), 0, s, idx, aabb, parents, (int)n, nodes, 0ull);   // the zero the kernel adds to read a slot atomically
 }
 void ptk_rearrange(const float4* in, const int32_t* idx, int64_t n, float4* out, hipStream_t s) {
     hipLaunchKernelGGL(k_rearrange, grid_for(n), dim3(PT_BLOCK), 0, s, in, idx, n, out);
