@@ -52,6 +52,7 @@ struct Mesh {
     float4* d_nodes = nullptr;        // per-mesh BLAS, child pointers relative to the mesh
     float4* d_tris_sorted = nullptr;  // Morton order
     int32_t* d_perm = nullptr;        // sorted position -> upload position
+    int32_t* d_dfs = nullptr;         // inner node -> its number in depth-first preorder (traversal-order copy of the BLAS)
     bool built = false, used = false; int64_t tri_offset = 0;
 };
 
@@ -69,6 +70,7 @@ struct pt_ctx {
     bool scene_built = false; int64_t n_tris = 0; int n_objects = 0; int n_meshes_used = 0; int32_t stack_bound = INT32_MAX;
     float4 *d_blas_nodes = nullptr, *d_blas_tris = nullptr, *d_tlas_nodes = nullptr, *d_objects = nullptr;
     float4* d_tri_records = nullptr;                    // SceneView::tris (edges + normal per packed triangle); d_blas_tris stays the reference's buffer
+    float4* d_blas_trav = nullptr;                      // SceneView::blas: the packed BLAS with inner nodes in depth-first order; d_blas_nodes stays the reference's
     int32_t* d_tlas_perm = nullptr;
     // render
     bool render_ready = false; RenderConst rc{}; PathState ps{};
@@ -153,27 +155,28 @@ int scene_stack_bound(pt_ctx* c) {
 int extend_variant_of(const pt_ctx* c) { return c->extend_variant >= 0 ? c->extend_variant : (c->n_objects > 1 ? 4 : 3); }
 
 SceneView scene_view(const pt_ctx* c) {
-    SceneView v; v.tlas = c->d_tlas_nodes; v.objects = c->d_objects; v.blas = c->d_blas_nodes; v.tris = c->d_tri_records;
+    SceneView v; v.tlas = c->d_tlas_nodes; v.objects = c->d_objects; v.blas = c->d_blas_trav ? c->d_blas_trav : c->d_blas_nodes; v.tris = c->d_tri_records;
     v.wide = c->traversal_mode == PT_TRAVERSAL_WIDE ? c->d_wide : nullptr;
     v.ext_mats = c->d_ext_mats; v.n_ext_mats = c->n_ext_mats; v.stack_bound = c->stack_bound;
     v.n_objects = c->n_objects; v.n_tris = (int32_t)std::min<int64_t>(c->n_tris, INT32_MAX);
     return v;
 }
 
-// builders.js:174-192: sort -> radix tree -> up pass.  aabb: 2 quads per primitive; keys are consumed.
-int build_bvh(pt_ctx* c, const float4* d_aabb, uint32_t* d_keys, int64_t n, int32_t* d_perm_out, float4* d_nodes_out) {
-    uint32_t* d_keys_sorted = nullptr; int32_t *d_iota = nullptr, *d_parents = nullptr; char* d_tmp = nullptr; size_t tmp_bytes = 0;
+// builders.js:174-192: sort -> radix tree -> up pass.  aabb: 2 quads per primitive.
+int build_bvh(pt_ctx* c, const float4* d_aabb, uint32_t* d_keys, int64_t n, int32_t* d_perm_out, float4* d_nodes_out, int32_t* d_dfs_out = nullptr) {
+    uint32_t* d_keys_sorted = nullptr; int32_t *d_parents = nullptr, *d_first = nullptr; char* d_tmp = nullptr; size_t tmp_bytes = 0;
     int rc = PT_OK; Tmp tmp;
     if ((rc = tmp.alloc(c, &d_keys_sorted, (size_t)n, false))) return rc;
-    if ((rc = tmp.alloc(c, &d_iota, (size_t)n, false))) return rc;
     if ((rc = tmp.alloc(c, &d_parents, (size_t)(2 * n), true))) return rc;
+    if (d_dfs_out && (rc = tmp.alloc(c, &d_first, (size_t)n, true))) return rc;
     HIPOK(c, hipMemsetAsync(d_nodes_out, 0, (size_t)n * 64, c->stream));   // WebGPU zero-fills BVH_BUFFER; f_1 is the arrival counter
-    ptk_iota(d_iota, n, c->stream);
-    HIPOK(c, pt_sort_pairs_u32(nullptr, &tmp_bytes, d_keys, d_keys_sorted, d_iota, d_perm_out, (size_t)n, c->stream));
+    // radix-sort.js:162-500: stable by key, carrying the position (its init_idx pass is folded into the first radix pass)
+    HIPOK(c, pt_sort_keys_index(nullptr, &tmp_bytes, d_keys, d_keys_sorted, d_perm_out, (size_t)n, c->stream));
     if ((rc = tmp.alloc(c, &d_tmp, std::max<size_t>(tmp_bytes, 16), false))) return rc;
-    HIPOK(c, pt_sort_pairs_u32(d_tmp, &tmp_bytes, d_keys, d_keys_sorted, d_iota, d_perm_out, (size_t)n, c->stream));
-    ptk_radix_tree(d_keys_sorted, n, d_parents, c->stream);
+    HIPOK(c, pt_sort_keys_index(d_tmp, &tmp_bytes, d_keys, d_keys_sorted, d_perm_out, (size_t)n, c->stream));
+    ptk_radix_tree(d_keys_sorted, n, d_parents, d_first, c->stream);
     ptk_up_pass(d_perm_out, d_aabb, d_parents, n, d_nodes_out, c->stream);
+    if (d_dfs_out) ptk_dfs_index(d_parents, d_first, n, d_dfs_out, c->stream);
     HIPOK(c, hipGetLastError());
     HIPOK(c, hipStreamSynchronize(c->stream));
     return PT_OK;
@@ -182,14 +185,15 @@ int build_bvh(pt_ctx* c, const float4* d_aabb, uint32_t* d_keys, int64_t n, int3
 // builders.js:153-214 buildMeshBVH
 int build_mesh(pt_ctx* c, Mesh& m) {
     float4* d_aabb = nullptr; uint32_t* d_keys = nullptr; int rc; Tmp tmp;
-    dfree(m.d_nodes); dfree(m.d_tris_sorted); dfree(m.d_perm); m.d_nodes = m.d_tris_sorted = nullptr; m.d_perm = nullptr;   // a failed earlier attempt
+    dfree(m.d_nodes); dfree(m.d_tris_sorted); dfree(m.d_perm); dfree(m.d_dfs); m.d_nodes = m.d_tris_sorted = nullptr; m.d_perm = m.d_dfs = nullptr;   // a failed earlier attempt
     if ((rc = tmp.alloc(c, &d_aabb, (size_t)m.n * 2, false))) return rc;
     if ((rc = tmp.alloc(c, &d_keys, (size_t)m.n, false))) return rc;
     if ((rc = dalloc(c, &m.d_nodes, (size_t)m.n * 4, false))) return rc;
     if ((rc = dalloc(c, &m.d_tris_sorted, (size_t)m.n * 3, false))) return rc;
     if ((rc = dalloc(c, &m.d_perm, (size_t)m.n, false))) return rc;
+    if ((rc = dalloc(c, &m.d_dfs, (size_t)m.n, false))) return rc;
     ptk_tri_aabb_morton(m.d_tris_in, m.n, m.bounds, d_aabb, d_keys, c->stream);
-    if ((rc = build_bvh(c, d_aabb, d_keys, m.n, m.d_perm, m.d_nodes))) return rc;
+    if ((rc = build_bvh(c, d_aabb, d_keys, m.n, m.d_perm, m.d_nodes, m.d_dfs))) return rc;
     ptk_rearrange(m.d_tris_in, m.d_perm, m.n, m.d_tris_sorted, c->stream);
     HIPOK(c, hipGetLastError());
     HIPOK(c, hipStreamSynchronize(c->stream));
@@ -200,12 +204,12 @@ int build_mesh(pt_ctx* c, Mesh& m) {
 void free_scene(pt_ctx* c) {
     if (c->scene_borrowed) {
         c->d_wide = nullptr;
-        c->d_blas_nodes = c->d_blas_tris = c->d_tlas_nodes = c->d_objects = c->d_tri_records = nullptr; c->d_tlas_perm = nullptr; c->scene_built = false;
+        c->d_blas_nodes = c->d_blas_tris = c->d_tlas_nodes = c->d_objects = c->d_tri_records = c->d_blas_trav = nullptr; c->d_tlas_perm = nullptr; c->scene_built = false;
         return;
     }
     if (c->d_wide) { dfree(c->d_wide); c->d_wide = nullptr; }
-    dfree(c->d_blas_nodes); dfree(c->d_blas_tris); dfree(c->d_tlas_nodes); dfree(c->d_objects); dfree(c->d_tlas_perm); dfree(c->d_tri_records);
-    c->d_blas_nodes = c->d_blas_tris = c->d_tlas_nodes = c->d_objects = c->d_tri_records = nullptr; c->d_tlas_perm = nullptr; c->scene_built = false;
+    dfree(c->d_blas_nodes); dfree(c->d_blas_tris); dfree(c->d_tlas_nodes); dfree(c->d_objects); dfree(c->d_tlas_perm); dfree(c->d_tri_records); dfree(c->d_blas_trav);
+    c->d_blas_nodes = c->d_blas_tris = c->d_tlas_nodes = c->d_objects = c->d_tri_records = c->d_blas_trav = nullptr; c->d_tlas_perm = nullptr; c->scene_built = false;
 }
 void free_render(pt_ctx* c) {
     for (auto& p : c->render_allocs) dfree(p.first);
@@ -319,7 +323,7 @@ int pt_create_sharing_scene(pt_ctx* src, pt_ctx** out) {
     c->scene_borrowed = true; c->scene_built = true; c->extend_variant = src->extend_variant;
     c->n_tris = src->n_tris; c->n_objects = src->n_objects; c->n_meshes_used = src->n_meshes_used; c->stack_bound = src->stack_bound;
     c->d_blas_nodes = src->d_blas_nodes; c->d_blas_tris = src->d_blas_tris; c->d_tlas_nodes = src->d_tlas_nodes; c->d_objects = src->d_objects;
-    c->d_tlas_perm = src->d_tlas_perm; c->d_tri_records = src->d_tri_records; c->d_wide = src->d_wide; c->traversal_mode = src->traversal_mode;
+    c->d_tlas_perm = src->d_tlas_perm; c->d_tri_records = src->d_tri_records; c->d_blas_trav = src->d_blas_trav; c->d_wide = src->d_wide; c->traversal_mode = src->traversal_mode;
     c->lender = src; src->borrowers.push_back(c);
     return PT_OK;
 }
@@ -331,7 +335,7 @@ int pt_destroy(pt_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     free_render(c); free_scene(c);
-    for (Mesh& m : c->meshes) { dfree(m.d_tris_in); dfree(m.d_nodes); dfree(m.d_tris_sorted); dfree(m.d_perm); }
+    for (Mesh& m : c->meshes) { dfree(m.d_tris_in); dfree(m.d_nodes); dfree(m.d_tris_sorted); dfree(m.d_perm); dfree(m.d_dfs); }
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return PT_OK;
@@ -402,6 +406,12 @@ int pt_scene_build(pt_ctx* c, const pt_instance* inst, int n_inst) {
         if (m.used) ptk_pack_mesh(m.d_nodes, m.d_tris_sorted, m.n, (int32_t)m.tri_offset, c->d_blas_nodes, c->d_blas_tris, c->stream);
     if ((rc = dalloc(c, &c->d_tri_records, (size_t)off * 3, false))) return rc;
     ptk_tri_records(c->d_blas_tris, off, c->d_tri_records, c->stream);
+    static const bool trav_order = !(getenv("PT_TRAVERSAL_ORDER") && atoi(getenv("PT_TRAVERSAL_ORDER")) == 0);   // measurement: 0 = walk the reference-order buffer
+    if (trav_order) {
+        if ((rc = dalloc(c, &c->d_blas_trav, (size_t)off * 4, false))) return rc;
+        for (Mesh& m : c->meshes)
+            if (m.used) ptk_reorder_nodes(c->d_blas_nodes, m.d_dfs, m.tri_offset, m.n, c->d_blas_trav, c->stream);
+    }
     // scene.js:42-61 scene bounds; builders.js:97-151 buildTLAS
     float sb[6] = {1e30f, 1e30f, 1e30f, -1e30f, -1e30f, -1e30f};
     std::vector<float> aabbs((size_t)n_inst * 8, 0.0f);

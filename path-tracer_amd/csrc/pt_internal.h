@@ -20,7 +20,7 @@
 struct SceneView {
     const float4* tlas;      // pt_bvh_node[n_objects]
     const float4* objects;   // pt_object[n_objects]
-    const float4* blas;      // pt_bvh_node[n_tris]
+    const float4* blas;      // pt_bvh_node[n_tris]: the traversal-order copy (k_reorder_nodes) unless PT_TRAVERSAL_ORDER=0
     const float4* tris;      // per triangle {v0, nx}{v1 - v0, ny}{v2 - v0, nz}: the reference's pt_triangle with what every ray
                              // would recompute from it -- the two edges (scene.js:479-481) and the unit normal
                              // (scene.js:233) -- evaluated once at build time by the same f32 operations (k_tri_records)
@@ -91,8 +91,10 @@ struct RenderConst {
 // ---- launchers (pt_kernels_build.hip) ---------------------------------------------------------
 void ptk_tri_aabb_morton(const float4* tris, int64_t n, const float bounds[6], float4* aabb, uint32_t* keys, hipStream_t s);
 void ptk_obj_morton(const float4* aabb, int64_t n, const float bounds[6], uint32_t* keys, hipStream_t s);
-void ptk_iota(int32_t* idx, int64_t n, hipStream_t s);
-void ptk_radix_tree(const uint32_t* sorted_keys, int64_t n, int32_t* parents /* 2n, zeroed */, hipStream_t s);
+void ptk_radix_tree(const uint32_t* sorted_keys, int64_t n, int32_t* parents /* 2n, zeroed */, int32_t* first /* n or null */, hipStream_t s);
+// traversal-order (depth-first preorder) numbering of a tree's inner nodes and the reordered copy of a packed mesh's nodes
+void ptk_dfs_index(const int32_t* parents, const int32_t* first, int64_t n, int32_t* dfs /* n */, hipStream_t s);
+void ptk_reorder_nodes(const float4* packed_nodes, const int32_t* dfs, int64_t offset, int64_t n, float4* trav_nodes, hipStream_t s);
 void ptk_up_pass(const int32_t* idx, const float4* aabb, const int32_t* parents, int64_t n, float4* nodes /* zeroed */, hipStream_t s);
 void ptk_rearrange(const float4* tris_in, const int32_t* idx, int64_t n, float4* tris_out, hipStream_t s);
 void ptk_tri_records(const float4* tris, int64_t n, float4* records, hipStream_t s);   // SceneView::tris from pt_triangle[n]
@@ -110,8 +112,9 @@ void ptk_pack_mesh(const float4* src_nodes, const float4* src_tris, int64_t n, i
 void ptk_collapse_wide(const float4* blas_nodes, int64_t offset, int64_t n, float4* wide, hipStream_t s);
 void ptk_pack_objects(const void* instances /* pt_instance[n] */, const int32_t* tlas_perm, const int32_t* mesh_tri_offset,
                       int n, float4* objects, hipStream_t s);
-hipError_t pt_sort_pairs_u32(void* tmp, size_t* tmp_bytes, const uint32_t* kin, uint32_t* kout,
-                             const int32_t* vin, int32_t* vout, size_t n, hipStream_t s);
+// pt_sort.hip: stable LSD radix sort of u32 keys; vout[i] = original position of the key that lands at i; kin is left alone.
+// tmp == null: only *tmp_bytes (two key-sized buffers + the digit histograms) is set.
+hipError_t pt_sort_keys_index(void* tmp, size_t* tmp_bytes, const uint32_t* kin, uint32_t* kout, int32_t* vout, size_t n, hipStream_t s);
 
 // ---- launchers (pt_kernels_render.hip) --------------------------------------------------------
 int  ptk_step_blocks(int num_paths);   // count records per step; the code array holds PT_STEP_BLOCK bytes per record, zero padded

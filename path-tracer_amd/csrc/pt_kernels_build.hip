@@ -1,7 +1,7 @@
 // pt_kernels_build.hip -- LBVH construction on gfx950.
 //
 // Pipeline per mesh (and once more over object boxes for the TLAS):
-//   boxes + 30-bit Morton keys -> stable key/index sort (rocPRIM, pt_sort.hip) -> Karras radix
+//   boxes + 30-bit Morton keys -> stable key/index radix sort (pt_sort.hip) -> Karras radix
 //   tree (parent links carry the child's side) -> bottom-up refit -> gather triangles -> pack.
 // All of it is HBM-streaming integer/f32 work; no LDS tiling or MFMA applies.  The refit is the
 // only inter-workgroup hand-off: device-scope atomics on both sides of one arrival counter.
@@ -48,12 +48,6 @@ __global__ __launch_bounds__(PT_BLOCK) void k_obj_morton(const float4* __restric
     if (i >= n) return;
     keys[i] = morton_of_box(F3(aabb[2 * i]), F3(aabb[2 * i + 1]), b);
 }
-// radix-sort.js:526-534 init_idx
-__global__ __launch_bounds__(PT_BLOCK) void k_iota(int32_t* __restrict__ idx, int64_t n) {
-    int64_t i = (int64_t)blockIdx.x * PT_BLOCK + threadIdx.x;
-    if (i < n) idx[i] = (int32_t)i;
-}
-
 // radix-tree.js:160-185: common-prefix length, equal keys fall back to the index bits
 __device__ __forceinline__ int del_(const uint32_t* __restrict__ keys, int n, int i1, int i2) {
     if (i2 < 0 || i2 >= n) return -1;
@@ -65,7 +59,8 @@ __device__ __forceinline__ int del_(const uint32_t* __restrict__ keys, int n, in
 // radix-tree.js:136-157 + :188-238.  One thread per inner node i.  Instead of a bare parent index the
 // link stores (parent << 1 | side) so that the refit can place each child in its Karras slot
 // (left = lower key range) without depending on arrival order.
-__global__ __launch_bounds__(PT_BLOCK) void k_radix_tree(const uint32_t* __restrict__ keys, int n, int32_t* __restrict__ parents) {
+// first (optional): the first leaf of node i's key range, for the traversal-order numbering (k_dfs_index).
+__global__ __launch_bounds__(PT_BLOCK) void k_radix_tree(const uint32_t* __restrict__ keys, int n, int32_t* __restrict__ parents, int32_t* __restrict__ first) {
     int i = blockIdx.x * PT_BLOCK + threadIdx.x;
     if (i >= n - 1) return;
     int a = del_(keys, n, i, i + 1) - del_(keys, n, i, i - 1);
@@ -87,6 +82,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_radix_tree(const uint32_t* __restr
     } while (t > 1);
     int gamma = i + s * d + min(d, 0);
     int lo = min(i, j), hi = max(i, j);
+    if (first) first[i] = lo;
     int left_slot  = (lo == gamma) ? n + gamma : gamma;           // leaf links live at parents[n + leaf]
     int right_slot = (hi == gamma + 1) ? n + gamma + 1 : gamma + 1;
     parents[left_slot]  = (i << 1);
@@ -195,10 +191,47 @@ void ptk_tri_aabb_morton(const float4* tris, int64_t n, const float bounds[6], f
 void ptk_obj_morton(const float4* aabb, int64_t n, const float bounds[6], uint32_t* keys, hipStream_t s) {
     hipLaunchKernelGGL(k_obj_morton, grid_for(n), dim3(PT_BLOCK), 0, s, aabb, n, mk_bounds(bounds), keys);
 }
-void ptk_iota(int32_t* idx, int64_t n, hipStream_t s) { hipLaunchKernelGGL(k_iota, grid_for(n), dim3(PT_BLOCK), 0, s, idx, n); }
-void ptk_radix_tree(const uint32_t* keys, int64_t n, int32_t* parents, hipStream_t s) {
+void ptk_radix_tree(const uint32_t* keys, int64_t n, int32_t* parents, int32_t* first, hipStream_t s) {
     if (n < 2) return;
-    hipLaunchKernelGGL(k_radix_tree, grid_for(n - 1), dim3(PT_BLOCK), 0, s, keys, (int)n, parents);
+    hipLaunchKernelGGL(k_radix_tree, grid_for(n - 1), dim3(PT_BLOCK), 0, s, keys, (int)n, parents, first);
+}
+// ---- traversal-order copy of a BLAS (no reference counterpart; never visible in a result) ----
+// The reference numbers an inner node by its position in the sorted keys (radix-tree.js: node i sits at an end of its range), so a
+// parent and its children are as far apart in memory as the range is wide.  The extend kernel reads a second copy of the packed
+// BLAS in which the inner nodes are numbered in depth-first preorder -- a node's left child is the next record, a subtree is one
+// contiguous block -- with the child pointers rewritten to match.  Same records, same walk, same hit indices (leaves keep their
+// triangle numbers); pt_get_blas_nodes keeps returning the reference's order.
+// preorder(i) = #ancestors + #inner nodes wholly to the left of i's range = first_leaf(i) + #ancestors in whose LEFT subtree i lies
+// (the leaves left of the range, first_leaf(i) of them, hang in the left-sibling subtrees of the other ancestors; a subtree of k
+// leaves has k - 1 inner nodes).
+__global__ __launch_bounds__(PT_BLOCK) void k_dfs_index(const int32_t* __restrict__ parents, const int32_t* __restrict__ first, int n, int32_t* __restrict__ dfs) {
+    int i = blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    if (i >= n - 1) { dfs[i] = i; return; }                 // the unused tail record of an n-leaf tree (and the whole one-leaf tree) stays put
+    int cnt = 0;
+    for (int p = i, guard = 0; p != 0 && guard < 64; guard++) { int link = parents[p]; cnt += (link & 1) == 0; p = link >> 1; }
+    dfs[i] = first[i] + cnt;
+}
+// one packed mesh: nodes [offset, offset + n) of `packed` (child pointers already rebased by pack-t-mesh.js:218-245) -> `trav`
+__global__ __launch_bounds__(PT_BLOCK) void k_reorder_nodes(const float4* __restrict__ packed, const int32_t* __restrict__ dfs, int64_t offset, int n, float4* __restrict__ trav) {
+    int i = blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float4* src = packed + 4 * (offset + i);
+    float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+    int lc = __float_as_int(q0.w), rc = __float_as_int(q2.w);
+    if (i < n - 1 || n == 1) {                              // a real node: its inner children move
+        if (lc >= 0) lc = (int)offset + dfs[lc - (int)offset];
+        if (rc >= 0) rc = (int)offset + dfs[rc - (int)offset];
+    }
+    q0.w = __int_as_float(lc); q2.w = __int_as_float(rc);
+    float4* dst = trav + 4 * (offset + dfs[i]);
+    dst[0] = q0; dst[1] = q1; dst[2] = q2; dst[3] = q3;
+}
+void ptk_dfs_index(const int32_t* parents, const int32_t* first, int64_t n, int32_t* dfs, hipStream_t s) {
+    hipLaunchKernelGGL(k_dfs_index, grid_for(n), dim3(PT_BLOCK), 0, s, parents, first, (int)n, dfs);
+}
+void ptk_reorder_nodes(const float4* packed, const int32_t* dfs, int64_t offset, int64_t n, float4* trav, hipStream_t s) {
+    hipLaunchKernelGGL(k_reorder_nodes, grid_for(n), dim3(PT_BLOCK), 0, s, packed, dfs, offset, (int)n, trav);
 }
 void ptk_up_pass(const int32_t* idx, const float4* aabb, const int32_t* parents, int64_t n, float4* nodes, hipStream_t s) {
     hipLaunchKernelGGL(k_up_pass, grid_for(n), dim3(PT_BLOCK), 0, s, idx, aabb, parents, (int)n, nodes, 0ull);   // the zero the kernel adds to read a slot atomically

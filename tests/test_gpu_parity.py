@@ -65,6 +65,27 @@ def test_bvh_layout_bit_exact(built, name):
     np.testing.assert_array_equal(s.objects_buffer(), o.objects_buffer())
 
 
+@pytest.mark.parametrize("n_tris", [1, 2, 3, 63, 64, 65, 1023, 1025, 4095, 4096, 4097, 8193, 70001])
+def test_sort_and_tree_at_tile_boundaries(pta, orc, n_tris):
+    """a11-a13 on mesh sizes around the radix sort's wave group (64), wave share (1024) and tile (4096), on a soup squeezed into a
+    few Morton cells so that most keys tie (a stable sort must keep tied keys in index order, radix-sort.js; the tree then
+    splits them by index, radix-tree.js:172-185): permutation and nodes equal the oracle's bit for bit."""
+    dev = pta.request_device(0)
+    try:
+        mesh = pta.scenes.random_soup(n_tris, 100 + n_tris, extent=0.05, size=0.04)
+        big = pta.scenes.random_soup(max(n_tris // 3, 1), 7, extent=3.0, size=0.3)          # spread keys: every digit of every pass in use
+        desc = {"meshes": [mesh, big], "instances": [(0, [0, 0, 0], [0, 0, 0], [1, 1, 1], 0), (1, [1, 0, 0], [0.1, 0, 0], [1, 1, 1], 1)], "camera": None}
+        s = pta.scenes.populate(pta.init_scene(dev), desc); s.build()
+        o = orc.OrcScene(desc)
+        for mi in (0, 1):
+            np.testing.assert_array_equal(s.mesh_perm(mi), o.mesh_perm(mi))
+        np.testing.assert_array_equal(s.tlas_perm(), o.tlas_perm())
+        np.testing.assert_array_equal(s.blas_nodes()[:, NODE_COLS], o.blas_nodes()[:, NODE_COLS])
+        np.testing.assert_array_equal(s.blas_tris().view(np.uint32), o.blas_tris().view(np.uint32))
+    finally:
+        dev.destroy()
+
+
 def rays_for(desc, n, seed):
     rng = np.random.default_rng(seed)
     cam = np.asarray(desc["camera"]["position"], np.float32)
