@@ -207,14 +207,14 @@ def single_pool(pta, dev, scene, desc, w, h, spp, paths):
 
 def roofline_pass(pta, dev, scene, desc, args, w, h, spp):
     """The extend kernel by itself: one pool (nothing overlaps its launches), one render that counts the algorithmic bytes
-    (counting variant, exact per-ray visit counts), then one render with HIP events on the launch stream around one launch in
-    sixteen.  Which ceiling binds is decided from the committed PMC passes of this same pool shape
+    (counting variant, exact per-ray visit counts), then one render with HIP events on the launch stream around every extend
+    launch.  Which ceiling binds is decided from the committed PMC passes of this same pool shape
     (profiles/roofline_<config>_1x<paths>.json, tools/pmc_passes.sh + tools/pmc_roofline.py): counters cannot be read inside a timed run."""
     paths = args.roofline_paths
     d2, pt = single_pool(pta, dev, scene, desc, w, h, spp, paths)
     try:
         rs_c = pt.run(count_bytes=True)
-        sec, rs, rays, ext_ms, timed = timed_renders(pt, 1, time_extend=True)
+        sec, rs, rays, ext_ms, timed = timed_renders(pt, 1, time_extend="all")
     finally:
         d2.destroy()
     launches = int(rs.steps)
@@ -232,16 +232,30 @@ def roofline_pass(pta, dev, scene, desc, args, w, h, spp):
         t_gbs = traffic / (pmc["rocprof_avg_launch_us"] * 1e-6) / 1e9
         ceilings["hbm_traffic"] = {"achieved": round(t_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(t_gbs / HBM_PEAK_GBS, 4),
                                    "what": "bytes that crossed the L2's memory side (TCC_EA0_RDREQ by size + WRITE_SIZE) / the profiled launch time"}
-        ceilings["valu"] = {"achieved": round(pmc["valu_busy"], 4), "peak": 1.0, "unit": "share of SIMD cycles with a VALU instruction active", "frac": round(pmc["valu_busy"], 4),
-                            "what": "SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * GRBM_GUI_ACTIVE / 8) over the whole launch, idle tail included; "
-                                    f"{pmc['valu_insts_per_launch'] / 1e6:.1f} M VALU instructions per launch"}
-    # the binding ceiling: the one the kernel is closest to, among those it cannot exceed (hbm_algorithmic can, when caches serve the nodes)
-    cand = {k: v for k, v in ceilings.items() if k != "hbm_algorithmic" or v["frac"] <= 1.0}
+        if "valu_cycles_per_inst" in pmc and avg_s > 0:
+            # instructions (committed counter pass of this pool shape) x their measured issue cost / the SIMD cycles of the launch as timed HERE
+            clock_hz = pmc["gpu_clock_ghz"] * 1e9
+            busy = pmc["valu_insts_per_launch"] * pmc["valu_cycles_per_inst"] / (1024 * avg_s * clock_hz)
+            ceilings["valu"] = {"achieved": round(busy, 4), "peak": 1.0, "unit": "share of SIMD cycles issuing VALU instructions", "frac": round(busy, 4),
+                                "counter_active_share": round(pmc["valu_busy"], 4),
+                                "what": f"{pmc['valu_insts_per_launch'] / 1e6:.1f} M VALU instructions per launch (SQ_INSTS_VALU) x {pmc['valu_cycles_per_inst']} cycles, the mean "
+                                        "measured issue cost of the traversal loop's instruction mix (tools/valu_mix.py, ubench table) / (1024 SIMDs x launch time x clock), "
+                                        "idle tail included.  counter_active_share = SQ_ACTIVE_INST_VALU * 4 / SIMD cycles, which overstates: it passes 1 when "
+                                        "instructions are added (profiles/r02_valu_sensitivity_sphere.txt: +22 % instructions cost +9 % launch time)"}
+        else:
+            ceilings["valu"] = {"achieved": round(pmc["valu_busy"], 4), "peak": 1.0, "unit": "share of SIMD cycles with a VALU instruction active", "frac": round(pmc["valu_busy"], 4),
+                                "what": "SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * GRBM_GUI_ACTIVE / 8) over the whole launch, idle tail included; "
+                                        f"{pmc['valu_insts_per_launch'] / 1e6:.1f} M VALU instructions per launch"}
+    # the binding ceiling: the physical one the kernel is closest to -- bytes that really crossed the memory side of the L2, or VALU
+    # issue.  hbm_algorithmic (the contract's bytes: every node record a ray consumes, priced as if it came from HBM) passes 1
+    # whenever the caches serve the nodes, so it is printed beside them and binds only when no counter pass is committed.
+    cand = {k: v for k, v in ceilings.items() if k != "hbm_algorithmic"} or ceilings
     bound = max(cand, key=lambda k: cand[k]["frac"])
     b = ceilings[bound]
     res = {"kernel": "k_extend_queue", "bound": {"hbm_algorithmic": "hbm", "hbm_traffic": "hbm", "valu": "valu"}[bound], "ceiling": bound,
            "achieved": b["achieved"], "peak": b["peak"], "unit": b["unit"], "frac": b["frac"], "traffic": traffic,
-           "timing": f"exclusive pass after the timed region: 1 pool of {paths} slots (launches of one pool never overlap), HIP events on the launch stream around 1 launch in 16",
+           "algorithmic_frac": ceilings["hbm_algorithmic"]["frac"],
+           "timing": f"exclusive pass after the timed region: 1 pool of {paths} slots (launches of one pool never overlap), HIP events on the launch stream around every launch",
            "avg_launch_us": round(avg_s * 1e6, 3), "launches_per_render": launches, "launches_timed": int(timed),
            "kernel_time_per_render_ms": round(avg_s * launches * 1e3, 3), "render_ms": round(sec * 1e3, 3),
            "Mrays_per_s": round(rays / sec / 1e6, 3), "algorithmic_bytes_per_launch": round(alg_bytes, 1),

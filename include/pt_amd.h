@@ -163,13 +163,14 @@ typedef struct {
     int64_t total_rays;         /* sum of stage-3 queue sizes */
     int64_t total_samples;      /* finished camera samples (= sum of image .w) */
     int64_t stack_overflows;    /* rays that hit the traversal guards (0 on sane scenes) */
-    double  extend_ms;          /* sum of the durations (HIP events) of the timed extend launches: one launch in sixteen */
+    double  extend_ms;          /* sum of the durations (HIP events) of the timed extend launches: one launch in sixteen, or all */
     int64_t extend_launches;    /* how many launches were timed */
     int64_t traversal_bytes;    /* algorithmic bytes if counted, else 0 */
     int64_t wasted_rays;        /* part of total_rays: rays traced for slots that ticket exhaustion had just retired
                                    (logic.js:177-190 pushes them to the camera queue regardless); one per retired slot */
 } pt_run_stats;
-enum { PT_RUN_TIME_EXTEND = 1, PT_RUN_COUNT_BYTES = 2 };
+enum { PT_RUN_TIME_EXTEND = 1, PT_RUN_COUNT_BYTES = 2,
+       PT_RUN_TIME_EXTEND_ALL = 4 /* events around every extend launch, not one in sixteen: for measuring the kernel, costs the render ~5 % */ };
 /* The reference's requestAnimationFrame loop (main.js:61-72) made headless: step until both
  * stage-2 queues are empty (or max_steps).  flags: PT_RUN_* . */
 int pt_render_run(pt_ctx* ctx, int64_t max_steps, int flags, pt_run_stats* out);

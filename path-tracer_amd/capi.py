@@ -10,6 +10,7 @@ LIB_PATH = os.environ.get("PT_AMD_LIB") or os.path.join(_HERE, "libpt_amd.so")  
 
 PT_RUN_TIME_EXTEND = 1
 PT_RUN_COUNT_BYTES = 2
+PT_RUN_TIME_EXTEND_ALL = 4
 
 
 class PtInstance(C.Structure):

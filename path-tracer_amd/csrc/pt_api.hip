@@ -657,29 +657,35 @@ int pt_render_step(pt_ctx* c, pt_step_stats* stats) {
 // PT_RUN_TIME_EXTEND: one extend launch in every second batch (one in sixteen) is bracketed by events, at a position that
 // rotates through the batch.  (Events around every launch were measured to cost 5.5 % of the render, around one in eight
 // still 2 % with three pools: each record is a barrier packet between two kernels of a step.)
+// PT_RUN_TIME_EXTEND_ALL: every extend launch is bracketed (for a pass that measures the kernel, not the render: bench.py's
+// exclusive roofline pass, where the mean over all launches is what a kernel trace of the same command shows).
 namespace {
-struct RunState { pt_ctx* c; double extend_ms = 0.0; int64_t launches = 0, issued = 0, last = 0; bool had_timed[2] = {false, false}, more = false, done = false; };
 const int POLL = 8;   // steps between looks at the queue sizes (the reference never looks: main.js:61-72)
-int run_issue(RunState& rs, int64_t batch, int64_t max_steps, bool timed, int count) {
+const int EV_PER_BATCH = 2 * POLL + 1;   // events of one batch parity: POLL {begin, end} pairs, then "header copy landed"
+struct RunState { pt_ctx* c; double extend_ms = 0.0; int64_t launches = 0, issued = 0, last = 0; unsigned had_timed[2] = {0u, 0u}; bool more = false, done = false; };
+int run_issue(RunState& rs, int64_t batch, int64_t max_steps, int timed /* 0, PT_RUN_TIME_EXTEND or PT_RUN_TIME_EXTEND_ALL */, int count) {
     pt_ctx* c = rs.c;
     HIPOK(c, hipSetDevice(c->device));        // the contexts may sit on different GPUs (one host thread drives them all)
-    int p = (int)(batch & 1); rs.had_timed[p] = false;
+    int p = (int)(batch & 1); rs.had_timed[p] = 0u;
+    hipEvent_t* ev = c->events.data() + EV_PER_BATCH * p;
     for (int k = 0; k < POLL && rs.issued < max_steps; k++, rs.issued++) {
-        bool t = timed && (batch & 1) == 0 && k == (int)((batch >> 1) % POLL);   // one launch in 2 * POLL
-        if (t) rs.had_timed[p] = true;
-        enqueue_step(c, count, t ? c->events[3 * p] : nullptr, t ? c->events[3 * p + 1] : nullptr);
+        bool t = timed == PT_RUN_TIME_EXTEND_ALL || (timed && (batch & 1) == 0 && k == (int)((batch >> 1) % POLL));   // one launch in 2 * POLL
+        if (t) rs.had_timed[p] |= 1u << k;
+        enqueue_step(c, count, t ? ev[2 * k] : nullptr, t ? ev[2 * k + 1] : nullptr);
     }
     HIPOK(c, hipGetLastError());
     HIPOK(c, hipMemcpyAsync(c->h_hdr + p, c->d_hdr, sizeof(StepHeader), hipMemcpyDeviceToHost, c->stream));
-    HIPOK(c, hipEventRecord(c->events[3 * p + 2], c->stream));
+    HIPOK(c, hipEventRecord(ev[2 * POLL], c->stream));
     return PT_OK;
 }
 int run_collect(RunState& rs, int64_t batch) {
     pt_ctx* c = rs.c;
     int p = (int)(batch & 1);
+    hipEvent_t* ev = c->events.data() + EV_PER_BATCH * p;
     HIPOK(c, hipSetDevice(c->device));
-    HIPOK(c, hipEventSynchronize(c->events[3 * p + 2]));
-    if (rs.had_timed[p]) { float ms = 0; HIPOK(c, hipEventElapsedTime(&ms, c->events[3 * p], c->events[3 * p + 1])); rs.extend_ms += ms; rs.launches++; }
+    HIPOK(c, hipEventSynchronize(ev[2 * POLL]));
+    for (int k = 0; k < POLL; k++)
+        if (rs.had_timed[p] >> k & 1u) { float ms = 0; HIPOK(c, hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1])); rs.extend_ms += ms; rs.launches++; }
     return PT_OK;
 }
 }  // namespace
@@ -691,7 +697,7 @@ int pt_render_run_many(pt_ctx** ctxs, int n, int64_t max_steps, int flags, pt_ru
         if (!ctxs[i]->render_ready) return fail(ctxs[i], PT_ERR_STATE, "pt_render_run: pt_render_init has not been called");
         for (int k = 0; k < i; k++) if (ctxs[k] == ctxs[i]) return fail(ctxs[i], PT_ERR_ARG, "pt_render_run_many: the same context twice");
     }
-    bool timed = (flags & PT_RUN_TIME_EXTEND) != 0; int count = (flags & PT_RUN_COUNT_BYTES) ? 1 : 0;
+    const int timed = (flags & PT_RUN_TIME_EXTEND_ALL) ? PT_RUN_TIME_EXTEND_ALL : (flags & PT_RUN_TIME_EXTEND); int count = (flags & PT_RUN_COUNT_BYTES) ? 1 : 0;
     if (max_steps <= 0) max_steps = INT64_MAX;
     std::vector<RunState> rs((size_t)n);
     int r;
@@ -700,8 +706,8 @@ int pt_render_run_many(pt_ctx** ctxs, int n, int64_t max_steps, int flags, pt_ru
         c->overlapped = false;
         for (int k = 0; k < n; k++) if (k != i && ctxs[k]->device == c->device) c->overlapped = true;   // another pool on this GPU
         HIPOK(c, hipSetDevice(c->device));
-        if (c->events.empty()) {   // per batch parity: [0,1] bracket a timed extend launch, [2] marks "header copy landed"
-            c->events.resize(6);
+        if (c->events.empty()) {   // per batch parity: {begin, end} per step of the batch for timed extend launches, then "header copy landed"
+            c->events.resize(2 * EV_PER_BATCH);
             for (hipEvent_t& e : c->events) HIPOK(c, hipEventCreate(&e));
         }
         if ((r = run_issue(rs[i], 0, max_steps, timed, count))) return r;

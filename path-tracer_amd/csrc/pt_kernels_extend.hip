@@ -211,6 +211,11 @@ __device__ __forceinline__ int op_inner(const SceneView& sc, Ray& r, const STK& 
     const float4* nd = (r.obj < 0 ? sc.tlas : sc.blas) + 4 * (int64_t)r.node;
     float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
     if (COUNT) r.n_inner++;
+#ifdef PT_EXTRA_VALU    // sensitivity experiment (tools/valu_sensitivity.sh): PT_EXTRA_VALU dependent adds per inner-node visit, results unchanged
+    { float acc = q1.w;
+#pragma unroll
+      for (int i = 0; i < PT_EXTRA_VALU; i++) asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc) : "v"(q3.w)); }
+#endif
     float l_dist = slab(F3(q0), F3(q1), r.o, r.id), r_dist = slab(F3(q2), F3(q3), r.o, r.id);
     bool l_valid = l_dist != -1e30f && l_dist < r.hit_dist;
     bool r_valid = r_dist != -1e30f && r_dist < r.hit_dist;

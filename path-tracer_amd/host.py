@@ -353,7 +353,7 @@ class PathTracer:
     def run(self, max_steps=0, time_extend=False, count_bytes=False):
         """main.js:61-72 frame loop, headless: step until both stage-2 queues are empty."""
         rs = capi.PtRunStats()
-        flags = (capi.PT_RUN_TIME_EXTEND if time_extend else 0) | (capi.PT_RUN_COUNT_BYTES if count_bytes else 0)
+        flags = ((capi.PT_RUN_TIME_EXTEND_ALL if time_extend == "all" else capi.PT_RUN_TIME_EXTEND) if time_extend else 0) | (capi.PT_RUN_COUNT_BYTES if count_bytes else 0)
         self.device.call("pt_render_run", int(max_steps), flags, C.byref(rs))
         return rs
 
@@ -425,7 +425,7 @@ class PooledPathTracer:
         n = len(self.pools)
         ctxs = (C.c_void_p * n)(*[pt.device.ctx for pt in self.pools])
         rs = (capi.PtRunStats * n)()
-        flags = (capi.PT_RUN_TIME_EXTEND if time_extend else 0) | (capi.PT_RUN_COUNT_BYTES if count_bytes else 0)
+        flags = ((capi.PT_RUN_TIME_EXTEND_ALL if time_extend == "all" else capi.PT_RUN_TIME_EXTEND) if time_extend else 0) | (capi.PT_RUN_COUNT_BYTES if count_bytes else 0)
         lib = self.device.lib
         capi.check(lib, self.device.ctx, lib.pt_render_run_many(ctxs, n, int(max_steps), flags, rs), "pt_render_run_many")
         out = capi.PtRunStats()

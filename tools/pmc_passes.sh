@@ -12,6 +12,10 @@ run_pass() {
   python3 tools/prof_summary.py gpurun_out/pmc_${tag}_${name}/r_results.db --pmc > gpurun_out/pmc_${tag}_${name}.txt
   rm -rf gpurun_out/pmc_${tag}_${name}     # the trace database is large; gpurun_out only travels back under 64 MiB
 }
+# first the same command with --kernel-trace only: the launch durations no counter collection has touched
+timeout -s KILL 240 rocprofv3 --kernel-trace --stats -d gpurun_out/pmc_${tag}_kt -o r -- python3 bench.py "$@" --no-cpu-baseline --no-extras > gpurun_out/pmc_${tag}_kt.json 2> gpurun_out/pmc_${tag}_kt.err
+python3 tools/prof_summary.py gpurun_out/pmc_${tag}_kt/r_results.db > gpurun_out/pmc_${tag}_kt.txt
+rm -rf gpurun_out/pmc_${tag}_kt
 run_pass sq1 "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" "$@"
 run_pass sq2 "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" "$@"
 run_pass tcc1 "FETCH_SIZE TCC_HIT_sum" "$@"
