@@ -37,6 +37,9 @@ CONFIGS = {
     "floor": ("floor_scene", {}, 512, 512, 16, 0),
     "grid": ("grid_scene", {}, 3840, 2160, 32, 3),              # 32 spp per GPU
     "instanced": ("instanced_scene", {}, 3840, 2160, 32, 4),
+    # configs[4] as BASELINE.json words it: mixed diffuse / specular / glossy materials and the 8-bounce cut (extensions, SURVEY 8f.1;
+    # the scene description carries them in desc["settings"])
+    "instanced_ext": ("instanced_scene_ext", {}, 3840, 2160, 32, 4),
 }
 
 
@@ -123,6 +126,7 @@ def main():
     image = torch.zeros(h * w * 4, dtype=torch.float32, device="cuda")
     settings = pta.multigpu.weak_share(rank, world, w, h, spp, args.paths, pools=args.pools)
     settings["imageDev"] = image.data_ptr()
+    settings.update(desc.get("settings", {}))       # a scene's extension materials and bounce cut
     pt = pta.init_path_tracer({"device": dev, "scene": scene, "image": {"width": w, "height": h}, "camera": desc["camera"], "settings": settings})
 
     def barrier():
@@ -168,12 +172,15 @@ def main():
             disp = pta.init_display({"device": dev, "canvas": args.png, "image": {"buffer": image.data_ptr(), "width": w, "height": h}})
             disp.draw()
         mode = ", FAST MODE: 4-wide BVH traversal, not bit-exact" if args.fast else ""
+        ext = desc.get("settings", {})
+        rules = (f"extension materials ({', '.join(sorted({m['type'] for m in ext['materials']}))}), bounce cut maxNb = {ext.get('maxNb')}"
+                 if ext.get("materials") else "reference bounce rules")
         out = {
             "metric": "Mrays/s", "value": round(all_rays / elapsed / 1e6, 3), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[{cfg_index}] {args.config}: {info.n_tris} tris / {info.n_objects} instances, {w}x{h}, {spp} spp per GPU, "
-                                   f"{args.pools} pool(s) of {args.paths} path slots (reference: 1 pool of 1000000), reference bounce rules{mode}",
+                                   f"{args.pools} pool(s) of {args.paths} path slots (reference: 1 pool of 1000000), {rules}{mode}",
                        "spp_total": spp * world, "parallelism": f"spp-split x{world}, RCCL sum-reduce of the accumulation buffer"},
             "samples_per_s": round(all_samples / elapsed, 1),
             "rays_per_render_per_gpu": rays // args.steps, "wavefront_iterations_per_render": int(steps_per_render),
@@ -201,7 +208,7 @@ def single_pool(pta, dev, scene, desc, w, h, spp, paths):
     """One more context on dev's GPU that borrows the built scene and holds ONE pool of `paths` slots with its own image."""
     d2 = pta.host.Device(sharing=dev)
     pt = pta.init_path_tracer({"device": d2, "scene": scene, "image": {"width": w, "height": h}, "camera": desc["camera"],
-                               "settings": {"samples": spp, "numPaths": paths}})
+                               "settings": dict({"samples": spp, "numPaths": paths}, **desc.get("settings", {}))})
     return d2, pt
 
 
@@ -308,7 +315,7 @@ def cpu_baseline(pta, desc, w, h, spp, paths):
     import orc
     threads = min(16, os.cpu_count() or 1)
     s = orc.OrcScene(desc)
-    r = orc.OrcRender(s, w, h, desc["camera"], spp, paths)
+    r = orc.OrcRender(s, w, h, desc["camera"], spp, paths, ext=desc.get("settings"))
     t0 = time.perf_counter()
     steps, rays, _ = r.run(threads=threads)
     dt = time.perf_counter() - t0
