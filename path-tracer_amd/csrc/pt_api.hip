@@ -52,7 +52,8 @@ struct Mesh {
     float4* d_nodes = nullptr;        // per-mesh BLAS, child pointers relative to the mesh
     float4* d_tris_sorted = nullptr;  // Morton order
     int32_t* d_perm = nullptr;        // sorted position -> upload position
-    int32_t* d_dfs = nullptr;         // inner node -> its number in depth-first preorder (traversal-order copy of the BLAS)
+    int32_t* d_dfs = nullptr;         // inner node -> its number in depth-first preorder (traversal-order copy of the BLAS);
+                                      // behind these n entries: PT_TOP_SLOTS + 1 ints, the nodes of the first levels by heap slot (k_dfs_index)
     bool built = false, used = false; int64_t tri_offset = 0;
 };
 
@@ -70,6 +71,7 @@ struct pt_ctx {
     bool scene_built = false; int64_t n_tris = 0; int n_objects = 0; int n_meshes_used = 0; int32_t stack_bound = INT32_MAX;
     float4 *d_blas_nodes = nullptr, *d_blas_tris = nullptr, *d_tlas_nodes = nullptr, *d_objects = nullptr;
     float4* d_tri_records = nullptr;                    // SceneView::tris (edges + normal per packed triangle); d_blas_tris stays the reference's buffer
+    float4* d_objects_top = nullptr; int32_t top_nodes = 0;   // tree-top blocks at node ids n_tris .. of d_blas_trav (SceneView::objects_top)
     float4* d_blas_trav = nullptr;                      // SceneView::blas: the packed BLAS with inner nodes in depth-first order; d_blas_nodes stays the reference's
     int32_t* d_tlas_perm = nullptr;
     // render
@@ -159,6 +161,8 @@ SceneView scene_view(const pt_ctx* c) {
     v.wide = c->traversal_mode == PT_TRAVERSAL_WIDE ? c->d_wide : nullptr;
     v.ext_mats = c->d_ext_mats; v.n_ext_mats = c->n_ext_mats; v.stack_bound = c->stack_bound;
     v.n_objects = c->n_objects; v.n_tris = (int32_t)std::min<int64_t>(c->n_tris, INT32_MAX);
+    const bool top = c->d_objects_top && !v.wide && v.blas == c->d_blas_trav;
+    v.objects_top = top ? c->d_objects_top : nullptr; v.top_base = top ? (int32_t)c->n_tris : INT32_MAX; v.top_nodes = top ? c->top_nodes : 0;
     return v;
 }
 
@@ -176,7 +180,10 @@ int build_bvh(pt_ctx* c, const float4* d_aabb, uint32_t* d_keys, int64_t n, int3
     HIPOK(c, pt_sort_keys_index(d_tmp, &tmp_bytes, d_keys, d_keys_sorted, d_perm_out, (size_t)n, c->stream));
     ptk_radix_tree(d_keys_sorted, n, d_parents, d_first, c->stream);
     ptk_up_pass(d_perm_out, d_aabb, d_parents, n, d_nodes_out, c->stream);
-    if (d_dfs_out) ptk_dfs_index(d_parents, d_first, n, d_dfs_out, c->stream);
+    if (d_dfs_out) {
+        HIPOK(c, hipMemsetAsync(d_dfs_out + n, 0xff, (PT_TOP_SLOTS + 1) * 4, c->stream));
+        ptk_dfs_index(d_parents, d_first, n, d_dfs_out, d_dfs_out + n, c->stream);
+    }
     HIPOK(c, hipGetLastError());
     HIPOK(c, hipStreamSynchronize(c->stream));
     return PT_OK;
@@ -191,7 +198,7 @@ int build_mesh(pt_ctx* c, Mesh& m) {
     if ((rc = dalloc(c, &m.d_nodes, (size_t)m.n * 4, false))) return rc;
     if ((rc = dalloc(c, &m.d_tris_sorted, (size_t)m.n * 3, false))) return rc;
     if ((rc = dalloc(c, &m.d_perm, (size_t)m.n, false))) return rc;
-    if ((rc = dalloc(c, &m.d_dfs, (size_t)m.n, false))) return rc;
+    if ((rc = dalloc(c, &m.d_dfs, (size_t)m.n + PT_TOP_SLOTS + 1, false))) return rc;
     ptk_tri_aabb_morton(m.d_tris_in, m.n, m.bounds, d_aabb, d_keys, c->stream);
     if ((rc = build_bvh(c, d_aabb, d_keys, m.n, m.d_perm, m.d_nodes, m.d_dfs))) return rc;
     ptk_rearrange(m.d_tris_in, m.d_perm, m.n, m.d_tris_sorted, c->stream);
@@ -205,10 +212,12 @@ void free_scene(pt_ctx* c) {
     if (c->scene_borrowed) {
         c->d_wide = nullptr;
         c->d_blas_nodes = c->d_blas_tris = c->d_tlas_nodes = c->d_objects = c->d_tri_records = c->d_blas_trav = nullptr; c->d_tlas_perm = nullptr; c->scene_built = false;
+        c->d_objects_top = nullptr; c->top_nodes = 0;
         return;
     }
     if (c->d_wide) { dfree(c->d_wide); c->d_wide = nullptr; }
     dfree(c->d_blas_nodes); dfree(c->d_blas_tris); dfree(c->d_tlas_nodes); dfree(c->d_objects); dfree(c->d_tlas_perm); dfree(c->d_tri_records); dfree(c->d_blas_trav);
+    dfree(c->d_objects_top); c->d_objects_top = nullptr; c->top_nodes = 0;
     c->d_blas_nodes = c->d_blas_tris = c->d_tlas_nodes = c->d_objects = c->d_tri_records = c->d_blas_trav = nullptr; c->d_tlas_perm = nullptr; c->scene_built = false;
 }
 void free_render(pt_ctx* c) {
@@ -323,7 +332,7 @@ int pt_create_sharing_scene(pt_ctx* src, pt_ctx** out) {
     c->scene_borrowed = true; c->scene_built = true; c->extend_variant = src->extend_variant;
     c->n_tris = src->n_tris; c->n_objects = src->n_objects; c->n_meshes_used = src->n_meshes_used; c->stack_bound = src->stack_bound;
     c->d_blas_nodes = src->d_blas_nodes; c->d_blas_tris = src->d_blas_tris; c->d_tlas_nodes = src->d_tlas_nodes; c->d_objects = src->d_objects;
-    c->d_tlas_perm = src->d_tlas_perm; c->d_tri_records = src->d_tri_records; c->d_blas_trav = src->d_blas_trav; c->d_wide = src->d_wide; c->traversal_mode = src->traversal_mode;
+    c->d_tlas_perm = src->d_tlas_perm; c->d_tri_records = src->d_tri_records; c->d_blas_trav = src->d_blas_trav; c->d_objects_top = src->d_objects_top; c->top_nodes = src->top_nodes; c->d_wide = src->d_wide; c->traversal_mode = src->traversal_mode;
     c->lender = src; src->borrowers.push_back(c);
     return PT_OK;
 }
@@ -407,10 +416,29 @@ int pt_scene_build(pt_ctx* c, const pt_instance* inst, int n_inst) {
     if ((rc = dalloc(c, &c->d_tri_records, (size_t)off * 3, false))) return rc;
     ptk_tri_records(c->d_blas_tris, off, c->d_tri_records, c->stream);
     static const bool trav_order = !(getenv("PT_TRAVERSAL_ORDER") && atoi(getenv("PT_TRAVERSAL_ORDER")) == 0);   // measurement: 0 = walk the reference-order buffer
+    // Tree-top blocks: as many levels of every used mesh's tree as fit in PT_SCENE_LDS_QUADS together with the TLAS and the objects
+    // (the extend variant that stages them in LDS); fewer than two levels are not worth a block.
+    int top_levels = 0;
+    if (trav_order)
+        for (int k = PT_TOP_LEVELS; k >= 2 && !top_levels; k--)
+            if (12 * (int64_t)n_inst + 4 * (int64_t)used * ((1 << k) - 1) <= PT_SCENE_LDS_QUADS) top_levels = k;
+    const int top_slots = top_levels ? (1 << top_levels) - 1 : 0;
+    std::vector<int32_t> mesh_root, top_root;
     if (trav_order) {
-        if ((rc = dalloc(c, &c->d_blas_trav, (size_t)off * 4, false))) return rc;
-        for (Mesh& m : c->meshes)
-            if (m.used) ptk_reorder_nodes(c->d_blas_nodes, m.d_dfs, m.tri_offset, m.n, c->d_blas_trav, c->stream);
+        if (off + (int64_t)used * top_slots > (1ll << 30)) top_levels = 0;
+        c->top_nodes = top_levels ? used * top_slots : 0;
+        if ((rc = dalloc(c, &c->d_blas_trav, (size_t)(off + c->top_nodes) * 4, false))) return rc;
+        int u = 0;
+        for (Mesh& m : c->meshes) {
+            if (!m.used) continue;
+            ptk_reorder_nodes(c->d_blas_nodes, m.d_dfs, m.tri_offset, m.n, c->d_blas_trav, c->stream);
+            if (top_levels) {
+                const int top_id = (int)(off + (int64_t)u * top_slots);
+                ptk_top_block(c->d_blas_nodes, m.d_dfs, m.d_dfs + m.n, m.tri_offset, m.n, top_levels, top_id, c->d_blas_trav, c->stream);
+                mesh_root.push_back((int32_t)m.tri_offset); top_root.push_back(top_id);
+            }
+            u++;
+        }
     }
     // scene.js:42-61 scene bounds; builders.js:97-151 buildTLAS
     float sb[6] = {1e30f, 1e30f, 1e30f, -1e30f, -1e30f, -1e30f};
@@ -434,6 +462,14 @@ int pt_scene_build(pt_ctx* c, const pt_instance* inst, int n_inst) {
     ptk_obj_morton(d_aabb, n_inst, sb, d_keys, c->stream);
     if ((rc = build_bvh(c, d_aabb, d_keys, n_inst, c->d_tlas_perm, c->d_tlas_nodes))) return rc;
     ptk_pack_objects(d_inst, c->d_tlas_perm, d_mesh_off, n_inst, c->d_objects, c->stream);
+    if (c->top_nodes) {
+        int32_t *d_mesh_root = nullptr, *d_top_root = nullptr;
+        if ((rc = tmp.alloc(c, &d_mesh_root, mesh_root.size(), false)) || (rc = tmp.alloc(c, &d_top_root, top_root.size(), false))) return rc;
+        if ((rc = dalloc(c, &c->d_objects_top, (size_t)n_inst * 8, false))) return rc;
+        HIPOK(c, hipMemcpyAsync(d_mesh_root, mesh_root.data(), mesh_root.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIPOK(c, hipMemcpyAsync(d_top_root, top_root.data(), top_root.size() * 4, hipMemcpyHostToDevice, c->stream));
+        ptk_objects_top(c->d_objects, n_inst, d_mesh_root, d_top_root, (int)mesh_root.size(), c->d_objects_top, c->stream);
+    }
     HIPOK(c, hipGetLastError());
     HIPOK(c, hipStreamSynchronize(c->stream));
     c->scene_built = true;

@@ -11,6 +11,8 @@
                                      // in an HBM spill; the render's extend variants choose their own split (pt_kernels_extend.hip)
 #define PT_SCENE_LDS_QUADS 512       // a scene of at most this many 16-B quads (12 per object + 7 per triangle) is staged in LDS
 #define PT_STAGED_LDS_STACK 12       // LDS stack entries per ray of the staged extend variant
+#define PT_TOP_LEVELS 7              // a mesh's tree-top block holds at most its first 7 levels (127 nodes, 8 KB); a scene uses as many
+#define PT_TOP_SLOTS 127             // levels as fit PT_SCENE_LDS_QUADS together with its TLAS and objects (pt_api.hip)
 #define PT_MAX_ITERS (1 << 20)       // traversal loop guard (degenerate N=1 trees can self-loop)
 #define PT_SAMPLES_PER_TICKET 8      // logic.js:6 SAMPLES_PER_PIXEL_PER_PATH
 
@@ -20,7 +22,7 @@
 struct SceneView {
     const float4* tlas;      // pt_bvh_node[n_objects]
     const float4* objects;   // pt_object[n_objects]
-    const float4* blas;      // pt_bvh_node[n_tris]: the traversal-order copy (k_reorder_nodes) unless PT_TRAVERSAL_ORDER=0
+    const float4* blas;      // pt_bvh_node[n_tris (+ top_nodes)]: the traversal-order copy (k_reorder_nodes) unless PT_TRAVERSAL_ORDER=0
     const float4* tris;      // per triangle {v0, nx}{v1 - v0, ny}{v2 - v0, nz}: the reference's pt_triangle with what every ray
                              // would recompute from it -- the two edges (scene.js:479-481) and the unit normal
                              // (scene.js:233) -- evaluated once at build time by the same f32 operations (k_tri_records)
@@ -30,6 +32,11 @@ struct SceneView {
     int32_t stack_bound;         // most stack entries any ray can hold in this scene (TLAS depth + deepest BLAS depth), or
                                  // INT32_MAX when unknown: only computed for scenes small enough to be staged in LDS
     int32_t n_objects, n_tris;   // record counts of the four buffers (the extend kernel stages tiny scenes in LDS)
+    // Tree-top blocks (k_top_block): node ids top_base .. top_base + top_nodes - 1 of `blas` hold the first levels of every mesh's
+    // tree by heap slot; objects_top = `objects` with the roots pointing there.  A launch that stages them in LDS walks from
+    // objects_top; every other launch walks from `objects` and never sees them.  top_nodes = 0: the scene has none.
+    const float4* objects_top;
+    int32_t top_base, top_nodes;
 };
 
 // PathState (path-tracer.js:131-160) as separate device arrays.  The vec3f members are stored as 12-byte records, not
@@ -93,7 +100,9 @@ void ptk_tri_aabb_morton(const float4* tris, int64_t n, const float bounds[6], f
 void ptk_obj_morton(const float4* aabb, int64_t n, const float bounds[6], uint32_t* keys, hipStream_t s);
 void ptk_radix_tree(const uint32_t* sorted_keys, int64_t n, int32_t* parents /* 2n, zeroed */, int32_t* first /* n or null */, hipStream_t s);
 // traversal-order (depth-first preorder) numbering of a tree's inner nodes and the reordered copy of a packed mesh's nodes
-void ptk_dfs_index(const int32_t* parents, const int32_t* first, int64_t n, int32_t* dfs /* n */, hipStream_t s);
+void ptk_dfs_index(const int32_t* parents, const int32_t* first, int64_t n, int32_t* dfs /* n */, int32_t* top_nodes /* PT_TOP_SLOTS, preset to -1, or null */, hipStream_t s);
+void ptk_top_block(const float4* packed_nodes, const int32_t* dfs, const int32_t* top_nodes, int64_t offset, int64_t n, int levels, int top_id, float4* trav_nodes, hipStream_t s);
+void ptk_objects_top(const float4* objects, int n, const int32_t* mesh_root, const int32_t* top_root, int n_meshes, float4* out, hipStream_t s);
 void ptk_reorder_nodes(const float4* packed_nodes, const int32_t* dfs, int64_t offset, int64_t n, float4* trav_nodes, hipStream_t s);
 void ptk_up_pass(const int32_t* idx, const float4* aabb, const int32_t* parents, int64_t n, float4* nodes /* zeroed */, hipStream_t s);
 void ptk_rearrange(const float4* tris_in, const int32_t* idx, int64_t n, float4* tris_out, hipStream_t s);

@@ -204,13 +204,58 @@ void ptk_radix_tree(const uint32_t* keys, int64_t n, int32_t* parents, int32_t* 
 // preorder(i) = #ancestors + #inner nodes wholly to the left of i's range = first_leaf(i) + #ancestors in whose LEFT subtree i lies
 // (the leaves left of the range, first_leaf(i) of them, hang in the left-sibling subtrees of the other ancestors; a subtree of k
 // leaves has k - 1 inner nodes).
-__global__ __launch_bounds__(PT_BLOCK) void k_dfs_index(const int32_t* __restrict__ parents, const int32_t* __restrict__ first, int n, int32_t* __restrict__ dfs) {
+// top_nodes (PT_TOP_SLOTS ints, preset to -1): the inner nodes of the first PT_TOP_LEVELS levels by heap slot -- root = 0, the
+// children of slot s = 2s + 1 (left), 2s + 2 (right) -- for the tree-top block of the traversal copy (k_top_block).
+__global__ __launch_bounds__(PT_BLOCK) void k_dfs_index(const int32_t* __restrict__ parents, const int32_t* __restrict__ first, int n, int32_t* __restrict__ dfs,
+                                                        int32_t* __restrict__ top_nodes) {
     int i = blockIdx.x * PT_BLOCK + threadIdx.x;
     if (i >= n) return;
+    if (i == 0 && top_nodes) top_nodes[0] = 0;              // the root (also of the one-leaf tree)
     if (i >= n - 1) { dfs[i] = i; return; }                 // the unused tail record of an n-leaf tree (and the whole one-leaf tree) stays put
-    int cnt = 0;
-    for (int p = i, guard = 0; p != 0 && guard < 64; guard++) { int link = parents[p]; cnt += (link & 1) == 0; p = link >> 1; }
+    int cnt = 0, depth = 0; unsigned path = 0u;             // path: bit j = the side taken j links above i (1 = right)
+    for (int p = i, guard = 0; p != 0 && guard < 64; guard++) {
+        int link = parents[p]; cnt += (link & 1) == 0;
+        if (depth < 31) path |= (unsigned)(link & 1) << depth;
+        depth++; p = link >> 1;
+    }
     dfs[i] = first[i] + cnt;
+    if (top_nodes && depth > 0 && depth < PT_TOP_LEVELS) top_nodes[(1 << depth) - 1 + (int)path] = i;
+}
+// The tree-top block of one packed mesh: the nodes of its first `levels` levels, by heap slot, at node ids top_id .. of `trav`
+// (behind the depth-first copy).  Children inside the block are linked by slot, the others by their depth-first ids, so a walk that
+// starts at top_id runs through the block and drops into the depth-first copy below it: the same records in the same order.
+// An extend launch stages the block in LDS (pt_kernels_extend.hip, TOP).  Unused slots are zero.
+__global__ void k_top_block(const float4* __restrict__ packed, const int32_t* __restrict__ dfs, const int32_t* __restrict__ top_nodes, int64_t offset, int n,
+                            int levels, int top_id, float4* __restrict__ trav) {
+    const int slots = (1 << levels) - 1, s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= slots) return;
+    float4* dst = trav + 4 * (int64_t)(top_id + s);
+    const int i = top_nodes[s];
+    if (i < 0) { dst[0] = dst[1] = dst[2] = dst[3] = make_float4(0.f, 0.f, 0.f, 0.f); return; }
+    const float4* src = packed + 4 * (offset + i);
+    float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+    int lc = __float_as_int(q0.w), rc = __float_as_int(q2.w);
+    auto moved = [&](int child, int slot) -> int {
+        if (child < 0) return child;                                         // a triangle
+        const int j = child - (int)offset;
+        if (slot < slots && top_nodes[slot] == j) return top_id + slot;      // inside the block
+        if (j == i) return top_id + s;                                       // the one-leaf tree's self pointer (pack-t-mesh.js keeps r = 0)
+        return (int)offset + dfs[j];
+    };
+    q0.w = __int_as_float(moved(lc, 2 * s + 1)); q2.w = __int_as_float(moved(rc, 2 * s + 2));
+    dst[0] = q0; dst[1] = q1; dst[2] = q2; dst[3] = q3;
+}
+// objects for a walk that starts in the tree-top blocks: pt_object[n] with the root node id (word 12) replaced
+__global__ void k_objects_top(const float4* __restrict__ objects, int n, const int32_t* __restrict__ mesh_root, const int32_t* __restrict__ top_root, int n_meshes,
+                              float4* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 8 * n) return;
+    float4 q = objects[i];
+    if ((i & 7) == 3) {
+        const int root = __float_as_int(q.x);
+        for (int k = 0; k < n_meshes; k++) if (mesh_root[k] == root) q.x = __int_as_float(top_root[k]);
+    }
+    out[i] = q;
 }
 // one packed mesh: nodes [offset, offset + n) of `packed` (child pointers already rebased by pack-t-mesh.js:218-245) -> `trav`
 __global__ __launch_bounds__(PT_BLOCK) void k_reorder_nodes(const float4* __restrict__ packed, const int32_t* __restrict__ dfs, int64_t offset, int n, float4* __restrict__ trav) {
@@ -227,8 +272,14 @@ __global__ __launch_bounds__(PT_BLOCK) void k_reorder_nodes(const float4* __rest
     float4* dst = trav + 4 * (offset + dfs[i]);
     dst[0] = q0; dst[1] = q1; dst[2] = q2; dst[3] = q3;
 }
-void ptk_dfs_index(const int32_t* parents, const int32_t* first, int64_t n, int32_t* dfs, hipStream_t s) {
-    hipLaunchKernelGGL(k_dfs_index, grid_for(n), dim3(PT_BLOCK), 0, s, parents, first, (int)n, dfs);
+void ptk_dfs_index(const int32_t* parents, const int32_t* first, int64_t n, int32_t* dfs, int32_t* top_nodes, hipStream_t s) {
+    hipLaunchKernelGGL(k_dfs_index, grid_for(n), dim3(PT_BLOCK), 0, s, parents, first, (int)n, dfs, top_nodes);
+}
+void ptk_top_block(const float4* packed, const int32_t* dfs, const int32_t* top_nodes, int64_t offset, int64_t n, int levels, int top_id, float4* trav, hipStream_t s) {
+    hipLaunchKernelGGL(k_top_block, dim3(1), dim3(PT_TOP_SLOTS + 1), 0, s, packed, dfs, top_nodes, offset, (int)n, levels, top_id, trav);
+}
+void ptk_objects_top(const float4* objects, int n, const int32_t* mesh_root, const int32_t* top_root, int n_meshes, float4* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_objects_top, dim3((unsigned)((8 * (int64_t)n + 255) / 256)), dim3(256), 0, s, objects, n, mesh_root, top_root, n_meshes, out);
 }
 void ptk_reorder_nodes(const float4* packed, const int32_t* dfs, int64_t offset, int64_t n, float4* trav, hipStream_t s) {
     hipLaunchKernelGGL(k_reorder_nodes, grid_for(n), dim3(PT_BLOCK), 0, s, packed, dfs, offset, (int)n, trav);

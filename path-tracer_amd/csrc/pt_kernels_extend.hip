@@ -205,11 +205,23 @@ __device__ __forceinline__ bool trip_guard(Ray& r) {
     if (!STK::shallow && r.iter > PT_MAX_ITERS) { r.overflow = 1; return false; }
     return true;
 }
-template <bool COUNT, class STK>
-__device__ __forceinline__ int op_inner(const SceneView& sc, Ray& r, const STK& stk) {      // :392-439
+// TOP: the TLAS and the tree-top blocks of the meshes are in LDS at `lds` ([tlas | objects | top blocks], staged by the kernel);
+// a node id >= sc.top_base is a slot of a top block.  The other BLAS nodes come from the depth-first copy in memory as ever.
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef const volatile __attribute__((address_space(3))) v4f* LdsQuads;   // typed as LDS, and volatile, so that the two fetch paths below stay two
+                                                                          // (the compiler otherwise merges them into flat loads through a select of addresses)
+template <bool COUNT, class STK, bool TOP = false>
+__device__ __forceinline__ int op_inner(const SceneView& sc, Ray& r, const STK& stk, LdsQuads lds = nullptr) {      // :392-439
     if (!trip_guard<STK>(r)) return PT_K_DONE;
-    const float4* nd = (r.obj < 0 ? sc.tlas : sc.blas) + 4 * (int64_t)r.node;
-    float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+    float4 q0, q1, q2, q3;
+    if (TOP && (r.obj < 0 || r.node >= sc.top_base)) {
+        LdsQuads nd = lds + (r.obj < 0 ? 4 * r.node : 12 * sc.n_objects + 4 * (r.node - sc.top_base));
+        const v4f a = nd[0], b = nd[1], c = nd[2], d = nd[3];
+        q0 = make_float4(a.x, a.y, a.z, a.w); q1 = make_float4(b.x, b.y, b.z, b.w); q2 = make_float4(c.x, c.y, c.z, c.w); q3 = make_float4(d.x, d.y, d.z, d.w);
+    } else {
+        const float4* nd = (!TOP && r.obj < 0 ? sc.tlas : sc.blas) + 4 * (int64_t)r.node;
+        q0 = nd[0]; q1 = nd[1]; q2 = nd[2]; q3 = nd[3];
+    }
     if (COUNT) r.n_inner++;
 #ifdef PT_EXTRA_VALU    // sensitivity experiment (tools/valu_sensitivity.sh): PT_EXTRA_VALU dependent adds per inner-node visit, results unchanged
     { float acc = q1.w;
@@ -257,14 +269,14 @@ __device__ __forceinline__ int op_switch(const SceneView& sc, Ray& r) {
     return kind_after(r);
 }
 // Runs the walk of every lane of the wave to its end.  `kind`: PT_K_INNER for a lane with a ray, PT_K_DONE for one without.
-template <bool COUNT, class STK>
-__device__ __forceinline__ void traverse_scheduled(const SceneView& sc, Ray& r, const STK& stk, int kind) {
+template <bool COUNT, class STK, bool TOP = false>
+__device__ __forceinline__ void traverse_scheduled(const SceneView& sc, Ray& r, const STK& stk, int kind, LdsQuads lds = nullptr) {
     for (;;) {
         const int ci = __popcll(__ballot(kind == PT_K_INNER)), cl = __popcll(__ballot(kind == PT_K_LEAF)), cs = __popcll(__ballot(kind == PT_K_SWITCH));
         if ((ci | cl | cs) == 0) break;
         // lanes advanced per instruction issued: the bodies cost about 1 : 1.4 : 2.4 (inner : triangle : switch)
         const int wi = ci * 12, wl = cl * 9, ws = cs * 5;
-        if (wi >= wl && wi >= ws) { if (kind == PT_K_INNER) kind = op_inner<COUNT, STK>(sc, r, stk); }
+        if (wi >= wl && wi >= ws) { if (kind == PT_K_INNER) kind = op_inner<COUNT, STK, TOP>(sc, r, stk, lds); }
         else if (wl >= ws)        { if (kind == PT_K_LEAF) kind = op_leaf<COUNT, STK>(sc, r, stk); }
         else                      { if (kind == PT_K_SWITCH) kind = op_switch<COUNT, STK>(sc, r); }
     }
@@ -310,7 +322,9 @@ __device__ __forceinline__ void publish(unsigned long long ov, unsigned long lon
 // SCENE_QUADS > 0: a scene whose four buffers together fit in SCENE_QUADS quads (12 per object + 7 per triangle) is copied
 // into LDS by every workgroup and traversed from there: the same records, an LDS read instead of an L1 round trip in
 // every link of the trip's dependent chain.
-template <int LDS_N, int BLOCK, bool COUNT, int ORDER, bool LOG, bool LOGIC, bool WIDE = false, int SCENE_QUADS = 0, bool SHALLOW = false, bool SCHED = false>
+// TOP (with SCHED; SCENE_QUADS is then the LDS budget, not a whole-scene limit): the TLAS, the objects and the tree-top blocks of the
+// meshes (SceneView::top_*) are staged instead of the whole scene, and the walk starts from objects_top (set by the launcher).
+template <int LDS_N, int BLOCK, bool COUNT, int ORDER, bool LOG, bool LOGIC, bool WIDE = false, int SCENE_QUADS = 0, bool SHALLOW = false, bool SCHED = false, bool TOP = false>
 __global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView sc, StepHeader* hdr, const int32_t* __restrict__ cam_q,
                                                         const int32_t* __restrict__ mat_q, int32_t* spill, int64_t spill_stride,
                                                         unsigned long long* wave_log, float* __restrict__ image, uint8_t* __restrict__ code_out,
@@ -329,7 +343,13 @@ __global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView 
     // take lets another one start in the wave slots that the finished waves of resident workgroups have already left.
     // (Sizing the stack part to the scene's stack bound as well was measured: the run-time LDS base costs more than it returns.)
     extern __shared__ float4 s_scene[];
-    if (SCENE_QUADS > 0) {                                       // [tlas | objects | blas | tris]
+    if (TOP) {                                                   // [tlas | objects (with top roots) | top blocks]
+        const int m4 = 4 * sc.n_objects, m12 = 12 * sc.n_objects, total = m12 + 4 * sc.top_nodes;
+        const float4* top = sc.blas + 4 * (int64_t)sc.top_base;
+        for (int i = threadIdx.x; i < total; i += BLOCK) s_scene[i] = i < m4 ? sc.tlas[i] : i < m12 ? sc.objects[i - m4] : top[i - m12];
+        __syncthreads();
+        sc.tlas = s_scene; sc.objects = s_scene + m4;
+    } else if (SCENE_QUADS > 0) {                                // [tlas | objects | blas | tris]
         const int m4 = 4 * sc.n_objects, m12 = 12 * sc.n_objects, n4 = 4 * sc.n_tris, total = m12 + 7 * sc.n_tris;
         for (int i = threadIdx.x; i < total; i += BLOCK)
             s_scene[i] = i < m4 ? sc.tlas[i] : i < m12 ? sc.objects[i - m4] : i < m12 + n4 ? sc.blas[i - m12] : sc.tris[i - m12 - n4];
@@ -350,7 +370,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView 
         ray_init(r, ro, rd);
         if (!SCHED) while (trav_step<COUNT, STK, WIDE>(sc, r, stk)) {}
     }
-    if (SCHED) traverse_scheduled<COUNT, STK>(sc, r, stk, q < n_rays ? PT_K_INNER : PT_K_DONE);     // the whole wave walks together
+    if (SCHED) traverse_scheduled<COUNT, STK, TOP>(sc, r, stk, q < n_rays ? PT_K_INNER : PT_K_DONE, (LdsQuads)s_scene);     // the whole wave walks together
     if (q < n_rays) {
         trav_finish<COUNT>(sc, r);
         ps.hit[path] = make_int2(r.hit_obj, r.hit_tri);
@@ -427,16 +447,17 @@ static int64_t pad_to(int64_t n, int64_t m) { return (n + m - 1) / m * m; }
 // The spill is sized for the smallest LDS share any variant uses (12 entries) and the largest slot count.
 size_t ptk_spill_ints(int64_t n_rays) { return (size_t)pad_to(n_rays, 256) * (PT_STACK_SIZE - PT_STAGED_LDS_STACK); }
 
-template <int LDS_N, int BLOCK, int ORDER, bool WIDE = false, int SCENE_QUADS = 0, bool SHALLOW = false, bool SCHED = false>
-static void launch_queue(const PathState& ps, int num_paths, int grid_rays, const SceneView& sc, StepHeader* hdr, const int32_t* cam_q,
+template <int LDS_N, int BLOCK, int ORDER, bool WIDE = false, int SCENE_QUADS = 0, bool SHALLOW = false, bool SCHED = false, bool TOP = false>
+static void launch_queue(const PathState& ps, int num_paths, int grid_rays, SceneView sc, StepHeader* hdr, const int32_t* cam_q,
                          const int32_t* mat_q, int32_t* spill, int count, unsigned long long* wave_log, float* image, uint8_t* code,
                          unsigned long long* rec_next, const RenderConst& rc, hipStream_t s) {
     int64_t stride = pad_to(num_paths, 256);
     // grid_rays: an upper bound of this step's queue length the host knows (the pool size until the tickets have run out; then
     // the last queue length it has seen: once no ticket is left, a step's rays are a subset of the step before's)
     dim3 grid((unsigned)((std::max(1, std::min(num_paths, grid_rays)) + BLOCK - 1) / BLOCK));
-    const size_t scene_lds = SCENE_QUADS > 0 ? 16 * (size_t)(12 * sc.n_objects + 7 * sc.n_tris) : 0;
-#define PT_LAUNCH(COUNT, LOG, LOGIC) hipLaunchKernelGGL((k_extend_queue<LDS_N, BLOCK, COUNT, ORDER, LOG, LOGIC, WIDE, SCENE_QUADS, SHALLOW, SCHED>), grid, dim3(BLOCK), scene_lds, s, ps, sc, hdr, \
+    const size_t scene_lds = TOP ? 16 * (size_t)(12 * sc.n_objects + 4 * sc.top_nodes) : SCENE_QUADS > 0 ? 16 * (size_t)(12 * sc.n_objects + 7 * sc.n_tris) : 0;
+    if (TOP) sc.objects = sc.objects_top;
+#define PT_LAUNCH(COUNT, LOG, LOGIC) hipLaunchKernelGGL((k_extend_queue<LDS_N, BLOCK, COUNT, ORDER, LOG, LOGIC, WIDE, SCENE_QUADS, SHALLOW, SCHED, TOP>), grid, dim3(BLOCK), scene_lds, s, ps, sc, hdr, \
                                                        cam_q, mat_q, spill, stride, wave_log, image, code, rec_next, rc)
     if (wave_log)    PT_LAUNCH(false, true, false);    // measurement replays (code == null): traversal only, idempotent
     else if (!code)  PT_LAUNCH(false, false, false);
@@ -461,9 +482,11 @@ static void launch_queue(const PathState& ps, int num_paths, int grid_rays, cons
 static const char* kVariantNames[] = {"256-thread workgroups, 24 LDS stack entries", "64-thread workgroups, 16 LDS stack entries",
                                       "64-thread workgroups, 16 LDS entries, class of the longest wave first",
                                       "as 2; a scene of <= 8 KB is staged in LDS (256-thread workgroups, 12 LDS stack entries)",
-                                      "as 3, kind-scheduled: each pass of the loop the wave runs the one body (inner node, triangle, object switch) that advances most lanes"};
-int ptk_extend_num_variants() { return 5; }
-const char* ptk_extend_variant_name(int v) { return (v >= 0 && v < 5) ? kVariantNames[v] : "?"; }
+                                      "as 3, kind-scheduled: each pass of the loop the wave runs the one body (inner node, triangle, object switch) that advances most lanes",
+                                      "as 4 with 256-thread workgroups and 12 LDS stack entries whatever the scene's size (the workgroup shape an LDS-staged tree top needs)",
+                                      "as 5; the TLAS, the objects and the first levels of every mesh's tree are staged in LDS (scenes too large to stage whole)"};
+int ptk_extend_num_variants() { return 7; }
+const char* ptk_extend_variant_name(int v) { return (v >= 0 && v < 7) ? kVariantNames[v] : "?"; }
 void ptk_extend_queue(const PathState& ps, const RenderConst& rc, const SceneView& sc, StepHeader* hdr, const int32_t* cam_q,
                       const int32_t* mat_q, int32_t* spill, int count, int variant, unsigned long long* wave_log, float* image, uint8_t* code,
                       unsigned long long* rec_next, int grid_rays, hipStream_t s) {
@@ -472,18 +495,21 @@ void ptk_extend_queue(const PathState& ps, const RenderConst& rc, const SceneVie
     else if (variant == 1) launch_queue<16, 64, 1>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
     else if (variant >= 3 && 12 * (int64_t)sc.n_objects + 7 * (int64_t)sc.n_tris <= PT_SCENE_LDS_QUADS) {
         if (sc.stack_bound <= PT_STAGED_LDS_STACK) {    // no ray's stack can leave LDS: no spill path, no overflow guard
-            if (variant == 4) launch_queue<PT_STAGED_LDS_STACK, 256, 2, false, PT_SCENE_LDS_QUADS, true, true>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
+            if (variant >= 4) launch_queue<PT_STAGED_LDS_STACK, 256, 2, false, PT_SCENE_LDS_QUADS, true, true>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
             else launch_queue<PT_STAGED_LDS_STACK, 256, 2, false, PT_SCENE_LDS_QUADS, true>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
         } else {
-            if (variant == 4) launch_queue<PT_STAGED_LDS_STACK, 256, 2, false, PT_SCENE_LDS_QUADS, false, true>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
+            if (variant >= 4) launch_queue<PT_STAGED_LDS_STACK, 256, 2, false, PT_SCENE_LDS_QUADS, false, true>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
             else launch_queue<PT_STAGED_LDS_STACK, 256, 2, false, PT_SCENE_LDS_QUADS>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
         }
     }
+    else if (variant == 6 && sc.top_nodes > 0 && sc.objects_top && 12 * (int64_t)sc.n_objects + 4 * (int64_t)sc.top_nodes <= PT_SCENE_LDS_QUADS)
+        launch_queue<PT_STAGED_LDS_STACK, 256, 2, false, PT_SCENE_LDS_QUADS, false, true, true>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
+    else if (variant >= 5) launch_queue<PT_STAGED_LDS_STACK, 256, 2, false, 0, false, true>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
     else if (variant == 4) launch_queue<16, 64, 2, false, 0, false, true>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
     else                   launch_queue<16, 64, 2>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
 }
 int64_t ptk_extend_waves(int num_paths, int variant) {
-    int block = (variant == 0 || variant >= 3) ? 256 : 64;   // variants 3 and 4 fall back to 64 when the scene does not fit: an upper bound then
+    int block = (variant == 0 || variant >= 3) ? 256 : 64;   // (variant 5 is always 256)   // variants 3 and 4 fall back to 64 when the scene does not fit: an upper bound then
     return (int64_t)((num_paths + block - 1) / block) * (block / 64);
 }
 size_t ptk_direct_spill_ints(int64_t n_rays) { return (size_t)pad_to(n_rays, 256) * (PT_STACK_SIZE - PT_LDS_STACK); }

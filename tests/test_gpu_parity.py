@@ -433,17 +433,17 @@ def test_fast_mode_render(pta, orc, device, built):
     np.testing.assert_allclose(img_e[..., :3], orr.image()[..., :3], rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
 def test_every_extend_variant_is_bit_exact(pta, orc, device, built, variant):
-    """The extend kernel's variants (workgroup shape, LDS/HBM stack split, dispatch order, tiny scene staged in LDS) never
-    change a result: whole path state against the oracle after each of 8 steps, on a scene that fits the LDS stage and on
-    one that does not."""
+    """The extend kernel's variants (workgroup shape, LDS/HBM stack split, dispatch order, kind scheduling, tiny scene or the tree
+    tops staged in LDS) never change a result: whole path state against the oracle after each of 8 steps, on a scene that fits
+    the LDS stage whole, on one whose two meshes get 5-level top blocks and on one with three instances of two meshes."""
     import ctypes as C
     name = C.create_string_buffer(200)
-    assert device.lib.pt_extend_variants(device.ctx, variant, name, 200) == 5 and name.value
+    assert device.lib.pt_extend_variants(device.ctx, variant, name, 200) == 7 and name.value
     try:
         device.call("pt_set_extend_variant", variant)
-        for scene_name, w, h, spp, paths in (("cornell", 64, 36, 8, 3000), ("sphere", 48, 32, 8, 2500)):
+        for scene_name, w, h, spp, paths in (("cornell", 64, 36, 8, 3000), ("sphere", 48, 32, 8, 2500), ("soup_ties", 48, 32, 8, 2500)):
             desc, s, o = built(scene_name)
             pt = pta.init_path_tracer({"device": device, "scene": s, "image": {"width": w, "height": h}, "camera": desc["camera"],
                                        "settings": {"samples": spp, "numPaths": paths}})
@@ -454,6 +454,46 @@ def test_every_extend_variant_is_bit_exact(pta, orc, device, built, variant):
                 assert_state_equal(pt, orr, step)
     finally:
         device.call("pt_set_extend_variant", -1)
+
+
+def test_tree_top_blocks_with_tiny_and_many_meshes(pta, orc):
+    """Extend variant 6 (TLAS, objects and the first levels of every mesh's tree staged in LDS) on the shapes its block builder has
+    to get right: a one-triangle mesh (the degenerate tree with its self pointer), a two-triangle mesh, a mesh shallower than the
+    block on one side, nine meshes (fewer levels fit), and a scene with too many objects for any block (falls back to variant 5).
+    Whole path state against the oracle after each step."""
+    one_tri = {"file": "v 0 0 0\nv 1 0 0\nv 0 1 0.3\nf 1 2 3\n"}
+    sc = pta.scenes
+    few = {"meshes": [sc.random_soup(3000, 11), one_tri, {"file": sc.FLOOR_OBJ}, sc.random_soup(5, 12)],
+           "instances": [(0, [0, 0, 1], [0.2, 0.1, 0], [1, 1, 1], 0), (1, [1, -2, 0.5], [0, 0, 0.5], [3, 3, 3], 1), (2, [0, 0, -1], [0, 0, 0], [1, 1, 1], 0),
+                         (3, [-2, 1, 2], [0.3, 0, 0], [0.5, 0.5, 0.5], 1), (1, [-3, -3, 1], [1, 0, 0], [4, 4, 4], 0)],
+           "camera": {"position": [2, -14, 5], "lookAt": [0, 0, 0.5], "fov": 35}}
+    nine = {"meshes": [sc.random_soup(200 + 37 * k, 20 + k) for k in range(9)],
+            "instances": [(k, [3 * (k % 3) - 3, 3 * (k // 3) - 3, 0], [0, 0, 0.1 * k], [0.4, 0.4, 0.4], k & 1) for k in range(9)],
+            "camera": {"position": [0, -16, 6], "lookAt": [0, 0, 0], "fov": 40}}
+    many = {"meshes": [sc.random_soup(400, 31)],
+            "instances": [(0, [2 * (k % 8) - 7, 2 * (k // 8) - 5, 0], [0, 0, 0.05 * k], [0.3, 0.3, 0.3], k & 1) for k in range(48)],
+            "camera": {"position": [0, -20, 8], "lookAt": [0, 0, 0], "fov": 40}}
+    dev = pta.request_device(0)
+    try:
+        dev.call("pt_set_extend_variant", 6)
+        for desc in (few, nine, many):
+            s = pta.scenes.populate(pta.init_scene(dev), desc); s.build()
+            o = orc.OrcScene(desc)
+            np.testing.assert_array_equal(s.objects_buffer(), o.objects_buffer())            # read-backs keep the reference's roots
+            np.testing.assert_array_equal(s.blas_nodes()[:, NODE_COLS], o.blas_nodes()[:, NODE_COLS])
+            pt = pta.init_path_tracer({"device": dev, "scene": s, "image": {"width": 48, "height": 32}, "camera": desc["camera"],
+                                       "settings": {"samples": 8, "numPaths": 2500}})
+            orr = orc.OrcRender(o, 48, 32, desc["camera"], 8, 2500)
+            hits = 0
+            for step in range(8):
+                gs = pt.step(); cs = orr.step_like_device()
+                assert (gs.n_camera, gs.n_material) == (cs.n_camera, cs.n_material)
+                assert_state_equal(pt, orr, step)
+                hits += int((pt.field("hit_obj") >= 0).sum())
+            assert hits > 100
+            pt.destroy()
+    finally:
+        dev.destroy()
 
 
 def test_error_behaviour(pta, device):
