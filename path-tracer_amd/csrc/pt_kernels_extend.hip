@@ -192,6 +192,11 @@ __device__ __forceinline__ bool trav_step(const SceneView& sc, Ray& r, const STK
 // on the one-object grid, so the library picks it only for scenes with more than one object (pt_api.hip).
 // --------------------------------------------------------------------------------------------
 enum { PT_K_INNER = 0, PT_K_LEAF = 1, PT_K_SWITCH = 2, PT_K_DONE = 3 };
+#ifndef PT_SCHED_WI      // weights of the three bodies in the choice of the next pass (tools/sched_weights.sh sweeps them)
+#define PT_SCHED_WI 6
+#define PT_SCHED_WL 9
+#define PT_SCHED_WS 5
+#endif
 __device__ __forceinline__ int kind_after(const Ray& r) {
     if (r.sp < 0) return PT_K_DONE;                             // the loop condition (scene.js:328)
     if (r.sp < r.switch_pt) return PT_K_SWITCH;                 // :330 the next trip begins by leaving the object
@@ -274,8 +279,11 @@ __device__ __forceinline__ void traverse_scheduled(const SceneView& sc, Ray& r, 
     for (;;) {
         const int ci = __popcll(__ballot(kind == PT_K_INNER)), cl = __popcll(__ballot(kind == PT_K_LEAF)), cs = __popcll(__ballot(kind == PT_K_SWITCH));
         if ((ci | cl | cs) == 0) break;
-        // lanes advanced per instruction issued: the bodies cost about 1 : 1.4 : 2.4 (inner : triangle : switch)
-        const int wi = ci * 12, wl = cl * 9, ws = cs * 5;
+        // The body that serves most lanes, weighted.  Weights by cost alone (lanes advanced per instruction issued: the bodies cost
+        // about 1 : 1.4 : 2.4, i.e. 12 : 9 : 5) were the first choice; the sweep (profiles/r02_sched_weight_sweep.txt) prefers the inner
+        // body at half that weight -- lanes parked at a triangle or an object switch then rejoin the others sooner: +3.7 % on the
+        // 82 k-triangle mesh, +6 % on the instanced scene, Cornell unchanged; below 4 it falls off again.
+        const int wi = ci * PT_SCHED_WI, wl = cl * PT_SCHED_WL, ws = cs * PT_SCHED_WS;
         if (wi >= wl && wi >= ws) { if (kind == PT_K_INNER) kind = op_inner<COUNT, STK, TOP>(sc, r, stk, lds); }
         else if (wl >= ws)        { if (kind == PT_K_LEAF) kind = op_leaf<COUNT, STK>(sc, r, stk); }
         else                      { if (kind == PT_K_SWITCH) kind = op_switch<COUNT, STK>(sc, r); }
