@@ -217,7 +217,10 @@ typedef const volatile __attribute__((address_space(3))) v4f* LdsQuads;   // typ
                                                                           // (the compiler otherwise merges them into flat loads through a select of addresses)
 template <bool COUNT, class STK, bool TOP = false>
 __device__ __forceinline__ int op_inner(const SceneView& sc, Ray& r, const STK& stk, LdsQuads lds = nullptr) {      // :392-439
-    if (!trip_guard<STK>(r)) return PT_K_DONE;
+    // One exit: a lane stopped by a guard runs the visit like the others (it changes no hit; its stack slot and node are its own and
+    // never read again) and is retired at the end.  Early returns here cost every lane of every pass a dozen register copies.
+    r.iter++;
+    const bool stop = !STK::shallow && r.iter > PT_MAX_ITERS;
     float4 q0, q1, q2, q3;
     if (TOP && (r.obj < 0 || r.node >= sc.top_base)) {
         LdsQuads nd = lds + (r.obj < 0 ? 4 * r.node : 12 * sc.n_objects + 4 * (r.node - sc.top_base));
@@ -227,7 +230,7 @@ __device__ __forceinline__ int op_inner(const SceneView& sc, Ray& r, const STK& 
         const float4* nd = (!TOP && r.obj < 0 ? sc.tlas : sc.blas) + 4 * (int64_t)r.node;
         q0 = nd[0]; q1 = nd[1]; q2 = nd[2]; q3 = nd[3];
     }
-    if (COUNT) r.n_inner++;
+    if (COUNT) r.n_inner += stop ? 0 : 1;
 #ifdef PT_EXTRA_VALU    // sensitivity experiment (tools/valu_sensitivity.sh): PT_EXTRA_VALU dependent adds per inner-node visit, results unchanged
     { float acc = q1.w;
 #pragma unroll
@@ -239,25 +242,28 @@ __device__ __forceinline__ int op_inner(const SceneView& sc, Ray& r, const STK& 
     int l_child = __float_as_int(q0.w), r_child = __float_as_int(q2.w);
     const bool both = l_valid && r_valid;
     const bool take_l = l_valid && (!r_valid || l_dist < r_dist);
-    if (both) {
-        if (!STK::shallow && __any(r.sp >= STK::lds_n) && r.sp >= PT_STACK_SIZE) { r.overflow = 1; return PT_K_DONE; }
+    const bool full = !STK::shallow && both && r.sp >= PT_STACK_SIZE;       // a push onto a full stack ends the ray
+    if (both && !full) {
         stk.put(r.sp, take_l ? r_child : l_child);
         r.sp += 1;
     }
     r.node = take_l ? l_child : r_child;
     if (!(l_valid || r_valid)) { r.sp -= 1; r.node = stk.get(r.sp); }
-    return kind_after(r);
+    if (!STK::shallow) r.overflow |= (stop || full) ? 1 : 0;
+    return (stop || full) ? PT_K_DONE : kind_after(r);
 }
 template <bool COUNT, class STK>
 __device__ __forceinline__ int op_leaf(const SceneView& sc, Ray& r, const STK& stk) {       // :380-391
-    if (!trip_guard<STK>(r)) return PT_K_DONE;
+    r.iter++;
+    const bool stop = !STK::shallow && r.iter > PT_MAX_ITERS;                // as in op_inner: one exit; a stopped lane's test changes nothing
     int t = -(r.node + 1);
     const float4* tr = sc.tris + 3 * (int64_t)t;
     float dist = tri_hit(r.o, r.d, tr[0], tr[1], tr[2]);
-    if (dist > 0.0f && dist < r.hit_dist) { r.hit_dist = dist; r.hit_tri = t; r.hit_obj = r.obj; }
-    if (COUNT) r.n_leaf++;
+    if (!stop && dist > 0.0f && dist < r.hit_dist) { r.hit_dist = dist; r.hit_tri = t; r.hit_obj = r.obj; }
+    if (COUNT) r.n_leaf += stop ? 0 : 1;
     r.sp -= 1; r.node = stk.get(r.sp);
-    return kind_after(r);
+    if (!STK::shallow) r.overflow |= stop ? 1 : 0;
+    return stop ? PT_K_DONE : kind_after(r);
 }
 // leaving (:330-355, rows 0-2 of the object = localToWorld) and entering (:357-379, rows 4-6 = worldToLocal, row 3 = root and
 // material) run the same arithmetic on different rows: one body serves both groups of lanes
