@@ -157,12 +157,13 @@ int scene_stack_bound(pt_ctx* c) {
 int extend_variant_of(const pt_ctx* c) { return c->extend_variant >= 0 ? c->extend_variant : (c->n_objects > 1 ? 4 : 3); }
 
 SceneView scene_view(const pt_ctx* c) {
-    SceneView v; v.tlas = c->d_tlas_nodes; v.objects = c->d_objects; v.blas = c->d_blas_trav ? c->d_blas_trav : c->d_blas_nodes; v.tris = c->d_tri_records;
+    SceneView v; v.nodes = c->d_blas_trav; v.objects = c->d_objects; v.tris = c->d_tri_records;
     v.wide = c->traversal_mode == PT_TRAVERSAL_WIDE ? c->d_wide : nullptr;
     v.ext_mats = c->d_ext_mats; v.n_ext_mats = c->n_ext_mats; v.stack_bound = c->stack_bound;
     v.n_objects = c->n_objects; v.n_tris = (int32_t)std::min<int64_t>(c->n_tris, INT32_MAX);
-    const bool top = c->d_objects_top && !v.wide && v.blas == c->d_blas_trav;
-    v.objects_top = top ? c->d_objects_top : nullptr; v.top_base = top ? (int32_t)c->n_tris : INT32_MAX; v.top_nodes = top ? c->top_nodes : 0;
+    v.tlas_root = v.n_tris;
+    const bool top = c->d_objects_top && !v.wide;
+    v.objects_top = top ? c->d_objects_top : nullptr; v.top_base = top ? v.n_tris + v.n_objects : INT32_MAX; v.top_nodes = top ? c->top_nodes : 0;
     return v;
 }
 
@@ -424,16 +425,17 @@ int pt_scene_build(pt_ctx* c, const pt_instance* inst, int n_inst) {
             if (12 * (int64_t)n_inst + 4 * (int64_t)used * ((1 << k) - 1) <= PT_SCENE_LDS_QUADS) top_levels = k;
     const int top_slots = top_levels ? (1 << top_levels) - 1 : 0;
     std::vector<int32_t> mesh_root, top_root;
-    if (trav_order) {
-        if (off + (int64_t)used * top_slots > (1ll << 30)) top_levels = 0;
+    {   // the walk's node array (SceneView::nodes): [BLAS | TLAS, rebased (further down, once it is built) | tree-top blocks]
+        if (off + n_inst + (int64_t)used * top_slots >= (1ll << 31)) return fail(c, PT_ERR_ARG, "pt_scene_build: more than 2^31 nodes");
         c->top_nodes = top_levels ? used * top_slots : 0;
-        if ((rc = dalloc(c, &c->d_blas_trav, (size_t)(off + c->top_nodes) * 4, false))) return rc;
+        if ((rc = dalloc(c, &c->d_blas_trav, (size_t)(off + n_inst + c->top_nodes) * 4, false))) return rc;
+        if (!trav_order) HIPOK(c, hipMemcpyAsync(c->d_blas_trav, c->d_blas_nodes, (size_t)off * 64, hipMemcpyDeviceToDevice, c->stream));
         int u = 0;
         for (Mesh& m : c->meshes) {
-            if (!m.used) continue;
+            if (!m.used || !trav_order) continue;
             ptk_reorder_nodes(c->d_blas_nodes, m.d_dfs, m.tri_offset, m.n, c->d_blas_trav, c->stream);
             if (top_levels) {
-                const int top_id = (int)(off + (int64_t)u * top_slots);
+                const int top_id = (int)(off + n_inst + (int64_t)u * top_slots);
                 ptk_top_block(c->d_blas_nodes, m.d_dfs, m.d_dfs + m.n, m.tri_offset, m.n, top_levels, top_id, c->d_blas_trav, c->stream);
                 mesh_root.push_back((int32_t)m.tri_offset); top_root.push_back(top_id);
             }
@@ -462,6 +464,7 @@ int pt_scene_build(pt_ctx* c, const pt_instance* inst, int n_inst) {
     ptk_obj_morton(d_aabb, n_inst, sb, d_keys, c->stream);
     if ((rc = build_bvh(c, d_aabb, d_keys, n_inst, c->d_tlas_perm, c->d_tlas_nodes))) return rc;
     ptk_pack_objects(d_inst, c->d_tlas_perm, d_mesh_off, n_inst, c->d_objects, c->stream);
+    ptk_tlas_rebase(c->d_tlas_nodes, n_inst, (int)off, c->d_blas_trav + 4 * off, c->stream);
     if (c->top_nodes) {
         int32_t *d_mesh_root = nullptr, *d_top_root = nullptr;
         if ((rc = tmp.alloc(c, &d_mesh_root, mesh_root.size(), false)) || (rc = tmp.alloc(c, &d_top_root, top_root.size(), false))) return rc;

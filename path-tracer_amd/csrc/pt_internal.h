@@ -20,9 +20,13 @@
 // The four scene buffers of the reference's bind group (scene.js:68-73), each addressed as
 // 16-byte quads: a 64-B node = 4 quads, a 48-B triangle = 3, a 128-B object = 8.
 struct SceneView {
-    const float4* tlas;      // pt_bvh_node[n_objects]
+    const float4* nodes;     // ONE node array for the walk (no reference counterpart; read-backs return the reference's two buffers):
+                             //   ids [0, n_tris)                      the packed BLAS, inner nodes in depth-first order (k_reorder_nodes;
+                             //                                        reference order with PT_TRAVERSAL_ORDER=0)
+                             //   ids [n_tris, n_tris + n_objects)     the TLAS, its inner links moved up by n_tris (k_tlas_rebase): a walk
+                             //                                        starts at tlas_root and never asks which tree a node id belongs to
+                             //   ids [top_base, top_base + top_nodes) tree-top blocks (below)
     const float4* objects;   // pt_object[n_objects]
-    const float4* blas;      // pt_bvh_node[n_tris (+ top_nodes)]: the traversal-order copy (k_reorder_nodes) unless PT_TRAVERSAL_ORDER=0
     const float4* tris;      // per triangle {v0, nx}{v1 - v0, ny}{v2 - v0, nz}: the reference's pt_triangle with what every ray
                              // would recompute from it -- the two edges (scene.js:479-481) and the unit normal
                              // (scene.js:233) -- evaluated once at build time by the same f32 operations (k_tri_records)
@@ -32,7 +36,8 @@ struct SceneView {
     int32_t stack_bound;         // most stack entries any ray can hold in this scene (TLAS depth + deepest BLAS depth), or
                                  // INT32_MAX when unknown: only computed for scenes small enough to be staged in LDS
     int32_t n_objects, n_tris;   // record counts of the four buffers (the extend kernel stages tiny scenes in LDS)
-    // Tree-top blocks (k_top_block): node ids top_base .. top_base + top_nodes - 1 of `blas` hold the first levels of every mesh's
+    int32_t tlas_root;           // = n_tris: the node id a walk starts at
+    // Tree-top blocks (k_top_block): node ids top_base .. top_base + top_nodes - 1 of `nodes` hold the first levels of every mesh's
     // tree by heap slot; objects_top = `objects` with the roots pointing there.  A launch that stages them in LDS walks from
     // objects_top; every other launch walks from `objects` and never sees them.  top_nodes = 0: the scene has none.
     const float4* objects_top;
@@ -102,6 +107,7 @@ void ptk_radix_tree(const uint32_t* sorted_keys, int64_t n, int32_t* parents /* 
 // traversal-order (depth-first preorder) numbering of a tree's inner nodes and the reordered copy of a packed mesh's nodes
 void ptk_dfs_index(const int32_t* parents, const int32_t* first, int64_t n, int32_t* dfs /* n */, int32_t* top_nodes /* PT_TOP_SLOTS, preset to -1, or null */, hipStream_t s);
 void ptk_top_block(const float4* packed_nodes, const int32_t* dfs, const int32_t* top_nodes, int64_t offset, int64_t n, int levels, int top_id, float4* trav_nodes, hipStream_t s);
+void ptk_tlas_rebase(const float4* tlas_nodes, int n, int delta, float4* out /* the TLAS part of SceneView::nodes */, hipStream_t s);
 void ptk_objects_top(const float4* objects, int n, const int32_t* mesh_root, const int32_t* top_root, int n_meshes, float4* out, hipStream_t s);
 void ptk_reorder_nodes(const float4* packed_nodes, const int32_t* dfs, int64_t offset, int64_t n, float4* trav_nodes, hipStream_t s);
 void ptk_up_pass(const int32_t* idx, const float4* aabb, const int32_t* parents, int64_t n, float4* nodes /* zeroed */, hipStream_t s);

@@ -245,6 +245,16 @@ __global__ void k_top_block(const float4* __restrict__ packed, const int32_t* __
     q0.w = __int_as_float(moved(lc, 2 * s + 1)); q2.w = __int_as_float(moved(rc, 2 * s + 2));
     dst[0] = q0; dst[1] = q1; dst[2] = q2; dst[3] = q3;
 }
+// the TLAS as part of the walk's one node array: pt_bvh_node[n] with the inner links moved up by `delta` (leaf links, < 0, name objects)
+__global__ void k_tlas_rebase(const float4* __restrict__ tlas, int n, int delta, float4* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 q0 = tlas[4 * i], q1 = tlas[4 * i + 1], q2 = tlas[4 * i + 2], q3 = tlas[4 * i + 3];
+    int lc = __float_as_int(q0.w), rc = __float_as_int(q2.w);
+    if (lc >= 0) q0.w = __int_as_float(lc + delta);
+    if (rc >= 0) q2.w = __int_as_float(rc + delta);
+    out[4 * i] = q0; out[4 * i + 1] = q1; out[4 * i + 2] = q2; out[4 * i + 3] = q3;
+}
 // objects for a walk that starts in the tree-top blocks: pt_object[n] with the root node id (word 12) replaced
 __global__ void k_objects_top(const float4* __restrict__ objects, int n, const int32_t* __restrict__ mesh_root, const int32_t* __restrict__ top_root, int n_meshes,
                               float4* __restrict__ out) {
@@ -277,6 +287,9 @@ void ptk_dfs_index(const int32_t* parents, const int32_t* first, int64_t n, int3
 }
 void ptk_top_block(const float4* packed, const int32_t* dfs, const int32_t* top_nodes, int64_t offset, int64_t n, int levels, int top_id, float4* trav, hipStream_t s) {
     hipLaunchKernelGGL(k_top_block, dim3(1), dim3(PT_TOP_SLOTS + 1), 0, s, packed, dfs, top_nodes, offset, (int)n, levels, top_id, trav);
+}
+void ptk_tlas_rebase(const float4* tlas, int n, int delta, float4* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_tlas_rebase, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, tlas, n, delta, out);
 }
 void ptk_objects_top(const float4* objects, int n, const int32_t* mesh_root, const int32_t* top_root, int n_meshes, float4* out, hipStream_t s) {
     hipLaunchKernelGGL(k_objects_top, dim3((unsigned)((8 * (int64_t)n + 255) / 256)), dim3(256), 0, s, objects, n, mesh_root, top_root, n_meshes, out);

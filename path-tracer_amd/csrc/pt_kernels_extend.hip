@@ -45,10 +45,10 @@ struct Ray {
     int n_inner, n_leaf, n_enter, n_leave, overflow;
 };
 
-__device__ __forceinline__ void ray_init(Ray& r, f3 o, f3 d) {
+__device__ __forceinline__ void ray_init(Ray& r, f3 o, f3 d, int root /* SceneView::tlas_root */) {
     r.o = o; r.d = d; r.id = rcp3(d);
     r.hit_dist = 1e6f; r.hit_obj = -1; r.hit_tri = -1;                       // scene.js:317-319
-    r.sp = 0; r.node = 0; r.obj = -1; r.switch_pt = -1; r.iter = 0;        // scene.js:321-324
+    r.sp = 0; r.node = root; r.obj = -1; r.switch_pt = -1; r.iter = 0;        // scene.js:321-324
     r.n_inner = r.n_leaf = r.n_enter = r.n_leave = 0; r.overflow = 0;
 }
 
@@ -155,7 +155,7 @@ __device__ __forceinline__ bool trav_step(const SceneView& sc, Ray& r, const STK
             r.node = r0;
         }
     } else {                                                    // :392-439 inner node
-        const float4* nd = (r.obj < 0 ? sc.tlas : sc.blas) + 4 * (int64_t)r.node;
+        const float4* nd = sc.nodes + 4 * (int64_t)r.node;     // TLAS and BLAS ids share one array (SceneView::nodes)
         float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
         if (COUNT) r.n_inner++;
         float l_dist = slab(F3(q0), F3(q1), r.o, r.id), r_dist = slab(F3(q2), F3(q3), r.o, r.id);
@@ -210,8 +210,8 @@ __device__ __forceinline__ bool trip_guard(Ray& r) {
     if (!STK::shallow && r.iter > PT_MAX_ITERS) { r.overflow = 1; return false; }
     return true;
 }
-// TOP: the TLAS and the tree-top blocks of the meshes are in LDS at `lds` ([tlas | objects | top blocks], staged by the kernel);
-// a node id >= sc.top_base is a slot of a top block.  The other BLAS nodes come from the depth-first copy in memory as ever.
+// TOP: the TLAS and the tree-top blocks of the meshes, node ids >= sc.n_tris, are in LDS at `lds` (staged by the kernel).
+// The other BLAS nodes come from the depth-first copy in memory as ever.
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef const volatile __attribute__((address_space(3))) v4f* LdsQuads;   // typed as LDS, and volatile, so that the two fetch paths below stay two
                                                                           // (the compiler otherwise merges them into flat loads through a select of addresses)
@@ -222,12 +222,12 @@ __device__ __forceinline__ int op_inner(const SceneView& sc, Ray& r, const STK& 
     r.iter++;
     const bool stop = !STK::shallow && r.iter > PT_MAX_ITERS;
     float4 q0, q1, q2, q3;
-    if (TOP && (r.obj < 0 || r.node >= sc.top_base)) {
-        LdsQuads nd = lds + (r.obj < 0 ? 4 * r.node : 12 * sc.n_objects + 4 * (r.node - sc.top_base));
+    if (TOP && r.node >= sc.n_tris) {
+        LdsQuads nd = lds + 4 * (r.node - sc.n_tris);
         const v4f a = nd[0], b = nd[1], c = nd[2], d = nd[3];
         q0 = make_float4(a.x, a.y, a.z, a.w); q1 = make_float4(b.x, b.y, b.z, b.w); q2 = make_float4(c.x, c.y, c.z, c.w); q3 = make_float4(d.x, d.y, d.z, d.w);
     } else {
-        const float4* nd = (!TOP && r.obj < 0 ? sc.tlas : sc.blas) + 4 * (int64_t)r.node;
+        const float4* nd = sc.nodes + 4 * (int64_t)r.node;
         q0 = nd[0]; q1 = nd[1]; q2 = nd[2]; q3 = nd[3];
     }
     if (COUNT) r.n_inner += stop ? 0 : 1;
@@ -357,21 +357,21 @@ __global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView 
     // take lets another one start in the wave slots that the finished waves of resident workgroups have already left.
     // (Sizing the stack part to the scene's stack bound as well was measured: the run-time LDS base costs more than it returns.)
     extern __shared__ float4 s_scene[];
-    if (TOP) {                                                   // [tlas | objects (with top roots) | top blocks]
-        const int m4 = 4 * sc.n_objects, m12 = 12 * sc.n_objects, total = m12 + 4 * sc.top_nodes;
-        const float4* top = sc.blas + 4 * (int64_t)sc.top_base;
-        for (int i = threadIdx.x; i < total; i += BLOCK) s_scene[i] = i < m4 ? sc.tlas[i] : i < m12 ? sc.objects[i - m4] : top[i - m12];
+    if (TOP) {                                                   // [nodes from id n_tris on: tlas, top blocks | objects (with top roots)]
+        const int t4 = 4 * (sc.n_objects + sc.top_nodes), total = t4 + 8 * sc.n_objects;
+        const float4* high = sc.nodes + 4 * (int64_t)sc.n_tris;
+        for (int i = threadIdx.x; i < total; i += BLOCK) s_scene[i] = i < t4 ? high[i] : sc.objects[i - t4];
         __syncthreads();
-        sc.tlas = s_scene; sc.objects = s_scene + m4;
-    } else if (SCENE_QUADS > 0) {                                // [tlas | objects | blas | tris]
-        const int m4 = 4 * sc.n_objects, m12 = 12 * sc.n_objects, n4 = 4 * sc.n_tris, total = m12 + 7 * sc.n_tris;
+        sc.objects = s_scene + t4;
+    } else if (SCENE_QUADS > 0) {                                // [nodes: blas, tlas | objects | tris]
+        const int n4 = 4 * (sc.n_tris + sc.n_objects), m8 = 8 * sc.n_objects, total = n4 + m8 + 3 * sc.n_tris;
         for (int i = threadIdx.x; i < total; i += BLOCK)
-            s_scene[i] = i < m4 ? sc.tlas[i] : i < m12 ? sc.objects[i - m4] : i < m12 + n4 ? sc.blas[i - m12] : sc.tris[i - m12 - n4];
+            s_scene[i] = i < n4 ? sc.nodes[i] : i < n4 + m8 ? sc.objects[i - n4] : sc.tris[i - n4 - m8];
         __syncthreads();
-        sc.tlas = s_scene; sc.objects = s_scene + m4; sc.blas = s_scene + m12; sc.tris = s_scene + m12 + n4;
+        sc.nodes = s_scene; sc.objects = s_scene + n4; sc.tris = s_scene + n4 + m8;
     }
     int q = blk * BLOCK + threadIdx.x;
-    Ray r; ray_init(r, F3(0, 0, 1), F3(0, 0, 1));
+    Ray r; ray_init(r, F3(0, 0, 1), F3(0, 0, 1), sc.tlas_root);
     unsigned code = 0u; int grp = -1;
     typedef Stack<LDS_N, BLOCK, SHALLOW> STK;
     STK stk{s_stack + threadIdx.x, spill + q, spill_stride};
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView 
         f3 ro, rd;
         if (LOGIC && q < n_cam) generate_one(ps, rc, path, ro, rd);          // camera.js:60-118; replays (no LOGIC) re-read the stored ray
         else { ro = F3(ps.path_o[path]); rd = F3(ps.path_d[path]); }
-        ray_init(r, ro, rd);
+        ray_init(r, ro, rd, sc.tlas_root);
         if (!SCHED) while (trav_step<COUNT, STK, WIDE>(sc, r, stk)) {}
     }
     if (SCHED) traverse_scheduled<COUNT, STK, TOP>(sc, r, stk, q < n_rays ? PT_K_INNER : PT_K_DONE, (LdsQuads)s_scene);     // the whole wave walks together
@@ -441,10 +441,10 @@ __global__ __launch_bounds__(PT_BLOCK) void k_extend_direct(SceneView sc, const 
                                                             int64_t spill_stride, StepHeader* hdr) {
     __shared__ int s_stack[PT_LDS_STACK * PT_BLOCK];
     int q = blockIdx.x * PT_BLOCK + threadIdx.x;
-    Ray r; ray_init(r, F3(0, 0, 1), F3(0, 0, 1));
+    Ray r; ray_init(r, F3(0, 0, 1), F3(0, 0, 1), sc.tlas_root);
     if (q < n) {
-        if (STRIDE == 4) ray_init(r, F3(((const float4*)o)[q]), F3(((const float4*)d)[q]));
-        else ray_init(r, F3(o[3 * (int64_t)q], o[3 * (int64_t)q + 1], o[3 * (int64_t)q + 2]), F3(d[3 * (int64_t)q], d[3 * (int64_t)q + 1], d[3 * (int64_t)q + 2]));
+        if (STRIDE == 4) ray_init(r, F3(((const float4*)o)[q]), F3(((const float4*)d)[q]), sc.tlas_root);
+        else ray_init(r, F3(o[3 * (int64_t)q], o[3 * (int64_t)q + 1], o[3 * (int64_t)q + 2]), F3(d[3 * (int64_t)q], d[3 * (int64_t)q + 1], d[3 * (int64_t)q + 2]), sc.tlas_root);
         Stack<PT_LDS_STACK, PT_BLOCK> stk{s_stack + threadIdx.x, spill + q, spill_stride};
         while (trav_step<true, Stack<PT_LDS_STACK, PT_BLOCK>, WIDE>(sc, r, stk)) {}
         trav_finish<true>(sc, r);
