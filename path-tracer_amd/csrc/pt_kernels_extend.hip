@@ -36,6 +36,7 @@ struct Stack {
         return sp < 0 ? 0 : (sp < LDS_N ? lds[sp * BLOCK] : spill[(int64_t)(sp - LDS_N) * stride]);
     }
     static constexpr int lds_n = LDS_N;
+    static constexpr int block = BLOCK;
 };
 
 struct Ray {
@@ -198,10 +199,10 @@ enum { PT_K_INNER = 0, PT_K_LEAF = 1, PT_K_SWITCH = 2, PT_K_DONE = 3 };
 #define PT_SCHED_WS 5
 #endif
 __device__ __forceinline__ int kind_after(const Ray& r) {
-    if (r.sp < 0) return PT_K_DONE;                             // the loop condition (scene.js:328)
-    if (r.sp < r.switch_pt) return PT_K_SWITCH;                 // :330 the next trip begins by leaving the object
-    if (r.node >= 0) return PT_K_INNER;
-    return r.obj < 0 ? PT_K_SWITCH : PT_K_LEAF;                 // :357 enter / :380 triangle
+    // three selects, no branches (the exec-mask bookkeeping of nested ifs costs the shared scalar unit more than the selects cost a SIMD)
+    int k = r.node >= 0 ? PT_K_INNER : (r.obj < 0 ? PT_K_SWITCH : PT_K_LEAF);   // :357 enter / :380 triangle
+    k = r.sp < r.switch_pt ? PT_K_SWITCH : k;                  // :330 the next trip begins by leaving the object
+    return r.sp < 0 ? PT_K_DONE : k;                           // the loop condition (scene.js:328)
 }
 // a trip = one INNER, LEAF or entering SWITCH; a leaving SWITCH belongs to the trip that follows it (r.iter counts trips, as in trav_step)
 template <class STK>
@@ -248,6 +249,8 @@ __device__ __forceinline__ int op_inner(const SceneView& sc, Ray& r, const STK& 
         r.sp += 1;
     }
     r.node = take_l ? l_child : r_child;
+    // (push and pop without branches -- every lane writes its first free slot and reads its top entry whenever all of them are in
+    // LDS -- was measured: -1 %, profiles/r02_instruction_cuts.txt)
     if (!(l_valid || r_valid)) { r.sp -= 1; r.node = stk.get(r.sp); }
     if (!STK::shallow) r.overflow |= (stop || full) ? 1 : 0;
     return (stop || full) ? PT_K_DONE : kind_after(r);
