@@ -285,17 +285,27 @@ __device__ __forceinline__ int op_switch(const SceneView& sc, Ray& r) {
 // Runs the walk of every lane of the wave to its end.  `kind`: PT_K_INNER for a lane with a ray, PT_K_DONE for one without.
 template <bool COUNT, class STK, bool TOP = false>
 __device__ __forceinline__ void traverse_scheduled(const SceneView& sc, Ray& r, const STK& stk, int kind, LdsQuads lds = nullptr) {
-    for (;;) {
-        const int ci = __popcll(__ballot(kind == PT_K_INNER)), cl = __popcll(__ballot(kind == PT_K_LEAF)), cs = __popcll(__ballot(kind == PT_K_SWITCH));
-        if ((ci | cl | cs) == 0) break;
-        // The body that serves most lanes, weighted.  Weights by cost alone (lanes advanced per instruction issued: the bodies cost
-        // about 1 : 1.4 : 2.4, i.e. 12 : 9 : 5) were the first choice; the sweep (profiles/r02_sched_weight_sweep.txt) prefers the inner
-        // body at half that weight -- lanes parked at a triangle or an object switch then rejoin the others sooner: +3.7 % on the
-        // 82 k-triangle mesh, +6 % on the instanced scene, Cornell unchanged; below 4 it falls off again.
-        const int wi = ci * PT_SCHED_WI, wl = cl * PT_SCHED_WL, ws = cs * PT_SCHED_WS;
-        if (wi >= wl && wi >= ws) { if (kind == PT_K_INNER) kind = op_inner<COUNT, STK, TOP>(sc, r, stk, lds); }
-        else if (wl >= ws)        { if (kind == PT_K_LEAF) kind = op_leaf<COUNT, STK>(sc, r, stk); }
-        else                      { if (kind == PT_K_SWITCH) kind = op_switch<COUNT, STK>(sc, r); }
+    // Same sequence of passes as "count, choose, run one body" in one loop; written as a tight loop per body inside the outer loop so
+    // that a run of passes of one kind keeps the values that body does not touch where they are (no copies at the joins).
+    int ci, cl, cs;
+    auto count = [&]() {
+        ci = __popcll(__ballot(kind == PT_K_INNER)) * PT_SCHED_WI; cl = __popcll(__ballot(kind == PT_K_LEAF)) * PT_SCHED_WL;
+        cs = __popcll(__ballot(kind == PT_K_SWITCH)) * PT_SCHED_WS;
+    };
+    // The body that serves most lanes, weighted.  Weights by cost alone (lanes advanced per instruction issued: the bodies cost
+    // about 1 : 1.4 : 2.4, i.e. 12 : 9 : 5) were the first choice; the sweep (profiles/r02_sched_weight_sweep.txt) prefers the inner
+    // body at half that weight -- lanes parked at a triangle or an object switch then rejoin the others sooner: +3.7 % on the
+    // 82 k-triangle mesh, +6 % on the instanced scene, Cornell unchanged; below 4 it falls off again.
+    count();
+    while ((ci | cl | cs) != 0) {
+        if (ci >= cl && ci >= cs) {
+            do { if (kind == PT_K_INNER) kind = op_inner<COUNT, STK, TOP>(sc, r, stk, lds); count(); } while (ci != 0 && ci >= cl && ci >= cs);
+        } else if (cl >= cs) {
+            do { if (kind == PT_K_LEAF) kind = op_leaf<COUNT, STK>(sc, r, stk); count(); } while (cl != 0 && ci < cl && cl >= cs);
+        } else {
+            if (kind == PT_K_SWITCH) kind = op_switch<COUNT, STK>(sc, r);
+            count();
+        }
     }
 }
 
