@@ -152,9 +152,9 @@ int scene_stack_bound(pt_ctx* c) {
     return PT_OK;
 }
 
-// Both: 8 waves/SIMD, class of the longest wave first, a tiny scene staged in LDS.  The kind-scheduled walk (4) pays where rays
-// switch between objects (+3...8 % measured with 2 to 101 objects) and costs 12 % on a one-object scene (pt_kernels_extend.hip).
-int extend_variant_of(const pt_ctx* c) { return c->extend_variant >= 0 ? c->extend_variant : (c->n_objects > 1 ? 4 : 3); }
+// 8 waves/SIMD, class of the longest wave first, a tiny scene staged in LDS, kind-scheduled walk: +7...13 % over variant 3 on scenes
+// with 2 to 101 objects and, with the inner body's weight at 3 (scene_view), +2.5 % on a one-object scene (profiles/r02_sched_weight_sweep.txt).
+int extend_variant_of(const pt_ctx* c) { return c->extend_variant >= 0 ? c->extend_variant : 4; }
 
 SceneView scene_view(const pt_ctx* c) {
     SceneView v; v.nodes = c->d_blas_trav; v.objects = c->d_objects; v.tris = c->d_tri_records;
@@ -162,6 +162,8 @@ SceneView scene_view(const pt_ctx* c) {
     v.ext_mats = c->d_ext_mats; v.n_ext_mats = c->n_ext_mats; v.stack_bound = c->stack_bound;
     v.n_objects = c->n_objects; v.n_tris = (int32_t)std::min<int64_t>(c->n_tris, INT32_MAX);
     v.tlas_root = v.n_tris;
+    static const int env_wi = getenv("PT_SCHED_WI") ? atoi(getenv("PT_SCHED_WI")) : 0;        // measurement override
+    v.sched_wi = env_wi > 0 ? env_wi : (c->n_objects > 1 ? 6 : 3);                           // profiles/r02_sched_weight_sweep.txt
     const bool top = c->d_objects_top && !v.wide;
     v.objects_top = top ? c->d_objects_top : nullptr; v.top_base = top ? v.n_tris + v.n_objects : INT32_MAX; v.top_nodes = top ? c->top_nodes : 0;
     return v;
@@ -318,7 +320,7 @@ int pt_create(int device_id, pt_ctx** out) {
         return fail(nullptr, PT_ERR_HIP, std::string("pt_create: hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
     }
     c->own_stream = true;
-    c->extend_variant = -1;  // automatic: variant 4 (kind-scheduled walk) for scenes with several objects, else 3 (scene_view)
+    c->extend_variant = -1;  // automatic: variant 4 (kind-scheduled walk)
     if (const char* v = getenv("PT_EXTEND_VARIANT")) c->extend_variant = atoi(v);
     *out = c;
     return PT_OK;

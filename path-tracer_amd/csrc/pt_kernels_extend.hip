@@ -193,8 +193,8 @@ __device__ __forceinline__ bool trav_step(const SceneView& sc, Ray& r, const STK
 // on the one-object grid, so the library picks it only for scenes with more than one object (pt_api.hip).
 // --------------------------------------------------------------------------------------------
 enum { PT_K_INNER = 0, PT_K_LEAF = 1, PT_K_SWITCH = 2, PT_K_DONE = 3 };
-#ifndef PT_SCHED_WI      // weights of the three bodies in the choice of the next pass (tools/sched_weights.sh sweeps them)
-#define PT_SCHED_WI 6
+// weights of the triangle and switch bodies in the choice of the next pass; the inner body's is SceneView::sched_wi (per scene)
+#ifndef PT_SCHED_WL
 #define PT_SCHED_WL 9
 #define PT_SCHED_WS 5
 #endif
@@ -289,13 +289,14 @@ __device__ __forceinline__ void traverse_scheduled(const SceneView& sc, Ray& r, 
     // that a run of passes of one kind keeps the values that body does not touch where they are (no copies at the joins).
     int ci, cl, cs;
     auto count = [&]() {
-        ci = __popcll(__ballot(kind == PT_K_INNER)) * PT_SCHED_WI; cl = __popcll(__ballot(kind == PT_K_LEAF)) * PT_SCHED_WL;
+        ci = __popcll(__ballot(kind == PT_K_INNER)) * sc.sched_wi; cl = __popcll(__ballot(kind == PT_K_LEAF)) * PT_SCHED_WL;
         cs = __popcll(__ballot(kind == PT_K_SWITCH)) * PT_SCHED_WS;
     };
     // The body that serves most lanes, weighted.  Weights by cost alone (lanes advanced per instruction issued: the bodies cost
     // about 1 : 1.4 : 2.4, i.e. 12 : 9 : 5) were the first choice; the sweep (profiles/r02_sched_weight_sweep.txt) prefers the inner
     // body at half that weight -- lanes parked at a triangle or an object switch then rejoin the others sooner: +3.7 % on the
-    // 82 k-triangle mesh, +6 % on the instanced scene, Cornell unchanged; below 4 it falls off again.
+    // 82 k-triangle mesh, +6 % on the instanced scene, Cornell unchanged; below 4 it falls off again -- except on a one-object scene,
+    // whose walk has no switches to wait for: there 3 is best (sc.sched_wi, set by the host: PT_SCHED_WI or 3).
     count();
     while ((ci | cl | cs) != 0) {
         if (ci >= cl && ci >= cs) {
