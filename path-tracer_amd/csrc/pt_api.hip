@@ -162,8 +162,11 @@ SceneView scene_view(const pt_ctx* c) {
     v.ext_mats = c->d_ext_mats; v.n_ext_mats = c->n_ext_mats; v.stack_bound = c->stack_bound;
     v.n_objects = c->n_objects; v.n_tris = (int32_t)std::min<int64_t>(c->n_tris, INT32_MAX);
     v.tlas_root = v.n_tris;
-    static const int env_wi = getenv("PT_SCHED_WI") ? atoi(getenv("PT_SCHED_WI")) : 0;        // measurement override
-    v.sched_wi = env_wi > 0 ? env_wi : (c->n_objects > 1 ? 6 : 3);                           // profiles/r02_sched_weight_sweep.txt
+    v.sched_wi = c->n_objects > 1 ? 6 : 3; v.sched_wl = 9; v.sched_ws = 5;                   // profiles/r02_sched_weight_sweep.txt
+    if (const char* w = getenv("PT_SCHED_W")) {                                              // measurement override: "inner,triangle,switch"
+        int a = 0, b = 0, d = 0;
+        if (sscanf(w, "%d,%d,%d", &a, &b, &d) == 3 && a > 0 && b > 0 && d > 0) { v.sched_wi = a; v.sched_wl = b; v.sched_ws = d; }
+    }
     const bool top = c->d_objects_top && !v.wide;
     v.objects_top = top ? c->d_objects_top : nullptr; v.top_base = top ? v.n_tris + v.n_objects : INT32_MAX; v.top_nodes = top ? c->top_nodes : 0;
     return v;

@@ -37,7 +37,7 @@ struct SceneView {
                                  // INT32_MAX when unknown: only computed for scenes small enough to be staged in LDS
     int32_t n_objects, n_tris;   // record counts of the four buffers (the extend kernel stages tiny scenes in LDS)
     int32_t tlas_root;           // = n_tris: the node id a walk starts at
-    int32_t sched_wi;            // kind-scheduled walk: weight of the inner-node body in the choice of a pass (pt_kernels_extend.hip)
+    int32_t sched_wi, sched_wl, sched_ws;   // kind-scheduled walk: weights of the inner-node, triangle and switch bodies in the choice of a pass
     // Tree-top blocks (k_top_block): node ids top_base .. top_base + top_nodes - 1 of `nodes` hold the first levels of every mesh's
     // tree by heap slot; objects_top = `objects` with the roots pointing there.  A launch that stages them in LDS walks from
     // objects_top; every other launch walks from `objects` and never sees them.  top_nodes = 0: the scene has none.

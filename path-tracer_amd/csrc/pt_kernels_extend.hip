@@ -193,11 +193,7 @@ __device__ __forceinline__ bool trav_step(const SceneView& sc, Ray& r, const STK
 // on the one-object grid, so the library picks it only for scenes with more than one object (pt_api.hip).
 // --------------------------------------------------------------------------------------------
 enum { PT_K_INNER = 0, PT_K_LEAF = 1, PT_K_SWITCH = 2, PT_K_DONE = 3 };
-// weights of the triangle and switch bodies in the choice of the next pass; the inner body's is SceneView::sched_wi (per scene)
-#ifndef PT_SCHED_WL
-#define PT_SCHED_WL 9
-#define PT_SCHED_WS 5
-#endif
+// the weights of the three bodies in the choice of the next pass are per scene: SceneView::sched_wi / wl / ws
 __device__ __forceinline__ int kind_after(const Ray& r) {
     // three selects, no branches (the exec-mask bookkeeping of nested ifs costs the shared scalar unit more than the selects cost a SIMD)
     int k = r.node >= 0 ? PT_K_INNER : (r.obj < 0 ? PT_K_SWITCH : PT_K_LEAF);   // :357 enter / :380 triangle
@@ -289,14 +285,14 @@ __device__ __forceinline__ void traverse_scheduled(const SceneView& sc, Ray& r, 
     // that a run of passes of one kind keeps the values that body does not touch where they are (no copies at the joins).
     int ci, cl, cs;
     auto count = [&]() {
-        ci = __popcll(__ballot(kind == PT_K_INNER)) * sc.sched_wi; cl = __popcll(__ballot(kind == PT_K_LEAF)) * PT_SCHED_WL;
-        cs = __popcll(__ballot(kind == PT_K_SWITCH)) * PT_SCHED_WS;
+        ci = __popcll(__ballot(kind == PT_K_INNER)) * sc.sched_wi; cl = __popcll(__ballot(kind == PT_K_LEAF)) * sc.sched_wl;
+        cs = __popcll(__ballot(kind == PT_K_SWITCH)) * sc.sched_ws;
     };
     // The body that serves most lanes, weighted.  Weights by cost alone (lanes advanced per instruction issued: the bodies cost
     // about 1 : 1.4 : 2.4, i.e. 12 : 9 : 5) were the first choice; the sweep (profiles/r02_sched_weight_sweep.txt) prefers the inner
     // body at half that weight -- lanes parked at a triangle or an object switch then rejoin the others sooner: +3.7 % on the
     // 82 k-triangle mesh, +6 % on the instanced scene, Cornell unchanged; below 4 it falls off again -- except on a one-object scene,
-    // whose walk has no switches to wait for: there 3 is best (sc.sched_wi, set by the host: PT_SCHED_WI or 3).
+    // whose walk has no switches to wait for: there 3 is best (sc.sched_wi, set by the host; PT_SCHED_W overrides).
     count();
     while ((ci | cl | cs) != 0) {
         if (ci >= cl && ci >= cs) {
