@@ -5,7 +5,7 @@
     hipcc --offload-arch=gfx950 <the Makefile's FLAGS> -S --cuda-device-only pt_kernels_extend.hip -o /tmp/ext.s
     tools/valu_mix.py /tmp/ext.s '<mangled-name substring>'      e.g. k_extend_queueILi16ELi64ELb0ELi2ELb0ELb1ELb0ELi0ELb0ELb1E
 
-Prints the mix of the first depth-1 loop of the kernel (the traversal loop) and the mean cycles per VALU instruction, the
+Prints the mix of the longest depth-1 loop of the kernel (the traversal loop) and the mean cycles per VALU instruction, the
 factor bench.py's `valu` ceiling uses instead of the nominal 4 (SQ_ACTIVE_INST_VALU x 4 exceeds the SIMD cycles when
 instructions are added: profiles/r02_valu_sensitivity_sphere.txt)."""
 import collections
@@ -30,11 +30,16 @@ def main():
     lines = open(sys.argv[1]).read().split("\n")
     start = next(i for i, l in enumerate(lines) if l.startswith("_Z") and sys.argv[2] in l and l.rstrip().endswith(":") or (l.startswith("_Z") and sys.argv[2] in l and ": " in l))
     end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
-    head = next(i for i in range(start, end) if "Inner Loop Header: Depth=1" in lines[i])
-    label = lines[head].split(":")[0].strip()
-    edges = [i for i in range(head, end) if re.search(r"s_c?branch\w*\s+" + re.escape(label) + r"\b", lines[i])]
-    # no branch straight back to the header (the back edge goes through a block in front of it): up to the next loop of the kernel
-    back = max(edges) if edges else next((i - 1 for i in range(head + 1, end) if "Loop Header: Depth=1" in lines[i]), end)
+    best = None                                                                           # the traversal loop is the kernel's longest depth-1 loop
+    for h in (i for i in range(start, end) if "Loop Header: Depth=1" in lines[i]):
+        name = lines[h].split(":")[0].strip().lstrip(".L")                                # comments name blocks without the ".L"
+        inside = [i for i in range(h, end) if f"Header={name} " in lines[i] or f"Parent Loop {name} " in lines[i]]
+        b = max(inside) if inside else h
+        while b + 1 < end and not re.match(r"\.LBB", lines[b + 1]):                       # to the end of the loop's last block
+            b += 1
+        if best is None or b - h > best[1] - best[0]:
+            best = (h, b)
+    head, back = best
     mix, mem = collections.Counter(), collections.Counter()
     for l in lines[head:back + 1]:
         m = re.match(r"\s+([a-z_0-9]+)", l)
