@@ -163,10 +163,11 @@ SceneView scene_view(const pt_ctx* c) {
     v.n_objects = c->n_objects; v.n_tris = (int32_t)std::min<int64_t>(c->n_tris, INT32_MAX);
     v.tlas_root = v.n_tris;
     v.sched_wi = c->n_objects > 1 ? 6 : 3; v.sched_wl = 9; v.sched_ws = 5;                   // profiles/r02_sched_weight_sweep.txt
-    if (const char* w = getenv("PT_SCHED_W")) {                                              // measurement override: "inner,triangle,switch"
-        int a = 0, b = 0, d = 0;
-        if (sscanf(w, "%d,%d,%d", &a, &b, &d) == 3 && a > 0 && b > 0 && d > 0) { v.sched_wi = a; v.sched_wl = b; v.sched_ws = d; }
-    }
+    static const struct EnvWeights {                                                         // measurement override: PT_SCHED_W="inner,triangle,switch"
+        int w[3] = {0, 0, 0};
+        EnvWeights() { const char* e = getenv("PT_SCHED_W"); if (!e || sscanf(e, "%d,%d,%d", &w[0], &w[1], &w[2]) != 3 || w[0] <= 0 || w[1] <= 0 || w[2] <= 0) w[0] = 0; }
+    } env;
+    if (env.w[0] > 0) { v.sched_wi = env.w[0]; v.sched_wl = env.w[1]; v.sched_ws = env.w[2]; }
     const bool top = c->d_objects_top && !v.wide;
     v.objects_top = top ? c->d_objects_top : nullptr; v.top_base = top ? v.n_tris + v.n_objects : INT32_MAX; v.top_nodes = top ? c->top_nodes : 0;
     return v;

@@ -181,6 +181,27 @@ def test_full_render_matches_oracle(pta, orc, device, built, name, w, h, spp, pa
     assert np.abs(t_g - t_c).max() <= 1
 
 
+@pytest.mark.parametrize("w,h,spp,paths", [(37, 23, 12, 1000), (16, 16, 1, 300), (1, 1, 8, 64), (3, 5, 20, 5000), (50, 40, 5, 4097)])
+def test_ragged_sample_counts_and_tiny_images(pta, orc, device, built, w, h, spp, paths):
+    """Edge cases of logic.js:177-183: the ticket count is ceil(W*H*spp / 8), so an spp that is not a multiple of 8 leaves some pixels
+    with 8 samples more than others; a pool larger than the whole job retires most slots at their first ticket; a one-pixel image.
+    Whole render against the oracle: steps, rays, sample counts per pixel, radiance."""
+    desc, s, o = built("cornell")
+    pt = pta.init_path_tracer({"device": device, "scene": s, "image": {"width": w, "height": h}, "camera": desc["camera"],
+                               "settings": {"samples": spp, "numPaths": paths}})
+    rs = pt.run()
+    orr = orc.OrcRender(o, w, h, desc["camera"], spp, paths)
+    steps, rays, _ = orr.run()
+    tickets = -(-w * h * spp // 8)
+    assert (rs.steps, rs.total_rays, rs.stack_overflows) == (steps, rays, 0)
+    assert rs.total_samples == 8 * tickets and rs.wasted_rays == paths
+    img_g, img_c = pt.read_image(), orr.image()
+    np.testing.assert_array_equal(img_g[..., 3], img_c[..., 3])
+    assert img_g[..., 3].sum() == 8 * tickets and set(np.unique(img_g[..., 3]).tolist()) <= {8.0 * (tickets // (w * h)), 8.0 * (tickets // (w * h) + 1)}
+    np.testing.assert_allclose(img_g[..., :3], img_c[..., :3], rtol=1e-5, atol=1e-6)
+    assert_state_equal(pt, orr, steps)
+
+
 def test_spp8_image_bit_exact(pta, orc, device, built):
     """With spp == 8 every pixel is owned by one slot for the whole render, so even the float add order is fixed."""
     desc, s, o = built("cornell")
