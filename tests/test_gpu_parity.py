@@ -126,6 +126,23 @@ def test_axis_aligned_and_degenerate_rays(built):
         np.testing.assert_array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b)
 
 
+def test_non_finite_and_empty_ray_batches(built):
+    """Rays nobody should send but a host can: zero direction (1/0 = inf in every slab term), NaN and infinite components in origin or
+    direction, unnormalised and denormal directions; and an empty batch.  Hit indices and visit counts equal the oracle's, hit distances
+    bit for bit except that a NaN may differ in payload (min/max pass NaNs through on both sides; the WGSL leaves them undefined)."""
+    desc, s, o = built("cornell")
+    inf, nan = np.inf, np.nan
+    ro = np.array([[0, -4, 1], [0, -4, 1], [0, -4, 1], [0, -4, 1], [nan, 0, 1], [0, inf, 1], [0, -4, 1], [0, -4, 1], [0, 0, 1], [0, -4, 1]], np.float32)
+    rd = np.array([[0, 0, 0], [nan, 1, 0], [0, inf, 0], [0, 1e-40, 0], [0, 1, 0], [0, 1, 0], [0, 250, 0], [0, 1e-20, 1e-20], [-0.0, 1, -0.0], [0, 1, 0]], np.float32)
+    g = s.trace_rays(ro, rd, counts=True); c = o.trace_rays(ro, rd, counts=True)
+    np.testing.assert_array_equal(g[0], c[0]); np.testing.assert_array_equal(g[1], c[1]); np.testing.assert_array_equal(g[3], c[3])
+    both_nan = np.isnan(g[2]) & np.isnan(c[2])
+    np.testing.assert_array_equal(g[2].view(np.uint32)[~both_nan], c[2].view(np.uint32)[~both_nan])
+    assert g[0][-1] >= 0                                                       # the last ray is an ordinary one and hits the box
+    e = s.trace_rays(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), counts=True)
+    assert all(len(x) == 0 for x in e)
+
+
 FIELDS = ["pixel_index", "num_bounces", "random_seed", "path_throughput", "material_throughput_pdf", "path_o", "path_d",
           "hit_obj", "hit_tri", "flags", "samples_in_pixel"]
 
