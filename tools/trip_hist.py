@@ -9,7 +9,7 @@ import bench
 ap = argparse.ArgumentParser(); ap.add_argument("--config", default="grid"); ap.add_argument("--warm-steps", type=int, default=200)
 a = ap.parse_args()
 pta = importlib.import_module("path-tracer_amd")
-factory, kwargs, w, h, spp = bench.CONFIGS[a.config]
+factory, kwargs, w, h, spp, _ = bench.CONFIGS[a.config]
 desc = getattr(pta.scenes, factory)(**kwargs)
 dev = pta.request_device(0)
 scene = pta.scenes.populate(pta.init_scene(dev), desc); scene.build()

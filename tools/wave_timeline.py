@@ -55,7 +55,7 @@ def main():
     ap.add_argument("--npz", default="")
     args = ap.parse_args()
     pta = importlib.import_module("path-tracer_amd")
-    factory, kwargs, w, h, spp = bench.CONFIGS[args.config]
+    factory, kwargs, w, h, spp, _ = bench.CONFIGS[args.config]
     desc = getattr(pta.scenes, factory)(**kwargs)
     dev = pta.request_device(0)
     scene = pta.scenes.populate(pta.init_scene(dev), desc); scene.build()
