@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--fast", action="store_true", help="fast mode: 4-wide BVH traversal (pt_set_traversal_mode; outside the bit-exact contract, reported separately)")
+    ap.add_argument("--check-period", type=int, default=-1, help="tolerance mode: one extend workgroup in N re-walks its rays exactly (library default 64; 1 = all, 0 = none)")
     ap.add_argument("--config", default="sphere", choices=sorted(CONFIGS))
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
@@ -119,6 +120,8 @@ def main():
     dev = pta.request_device(gpu, stream=stream)
     if args.fast:
         dev.call("pt_set_traversal_mode", pta.capi.PT_TRAVERSAL_WIDE)
+        if args.check_period >= 0:
+            dev.call("pt_set_traversal_check", args.check_period)
     desc, scene, build_s = build_scene(pta, dev, args.config)
     info = scene.info()
 
@@ -148,10 +151,12 @@ def main():
         one_step()
     barrier()
     t0 = time.perf_counter()
-    rays = samples = wasted = 0
+    rays = samples = wasted = checked = mismatched = flipped = beyond = lost = 0
+    max_rel = 0.0
     for _ in range(args.steps):
         rs = one_step()
         rays += rs.total_rays; samples += rs.total_samples; wasted += rs.wasted_rays
+        checked += rs.checked_rays; mismatched += rs.mismatched_rays; flipped += rs.flipped_rays; beyond += rs.beyond_tolerance_rays; lost += rs.lost_hit_rays; max_rel = max(max_rel, rs.max_rel_dist_diff)
         steps_per_render = rs.steps
         if rs.stack_overflows:
             raise SystemExit(f"traversal guard hit on {rs.stack_overflows} rays")
@@ -189,6 +194,9 @@ def main():
             "wasted_rays_per_render_per_gpu": wasted // args.steps, "useful_Mrays_per_s": round((all_rays - all_wasted) / elapsed / 1e6, 3),
             "scene_build_s": round(build_s, 3),
         }
+        if args.fast:
+            out["tolerance_check"] = {"rays_rewalked_exactly": checked, "different_hit": mismatched, "hit_vs_miss": flipped, "beyond_1e-6": beyond, "of_those_reference_hit_lost": lost, "max_rel_hit_dist_diff": max_rel,
+                                      "share_rewalked": round(checked / max(rays, 1), 5)}
         if not args.no_extras:
             out["roofline"] = roofline_pass(pta, dev, scene, desc, args, w, h, spp)
             out["reference_pool_shape"] = reference_shape_pass(pta, dev, scene, desc, w, h, spp)

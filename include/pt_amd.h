@@ -168,6 +168,15 @@ typedef struct {
     int64_t traversal_bytes;    /* algorithmic bytes if counted, else 0 */
     int64_t wasted_rays;        /* part of total_rays: rays traced for slots that ticket exhaustion had just retired
                                    (logic.js:177-190 pushes them to the camera queue regardless); one per retired slot */
+    /* tolerance mode only (PT_TRAVERSAL_WIDE; all 0 otherwise): what the sampled exact re-walks found (pt_set_traversal_check) */
+    int64_t checked_rays;       /* rays of this render that were walked a second time, exactly as the reference walks them */
+    int64_t mismatched_rays;    /* of those: the two walks returned a different (hit_obj, hit_tri) */
+    int64_t flipped_rays;       /* of the mismatched: one walk hit and the other missed */
+    double  max_rel_dist_diff;  /* largest |hit_dist - exact hit_dist| / exact hit_dist over the checked rays that both walks hit */
+    int64_t beyond_tolerance_rays; /* checked rays whose two hit_dist differ by more than 1e-6 relative, flipped rays included: north_star
+                                      allows differing indices "within 1e-6"; these are the rays outside that allowance */
+    int64_t lost_hit_rays;      /* of those: the tolerance mode's hit is the FARTHER one (or a miss): a hit the reference finds was lost.
+                                   The others found a closer hit than the reference walk, whose own box test had culled it */
 } pt_run_stats;
 enum { PT_RUN_TIME_EXTEND = 1, PT_RUN_COUNT_BYTES = 2,
        PT_RUN_TIME_EXTEND_ALL = 4 /* events around every extend launch, not one in sixteen: for measuring the kernel, costs the render ~5 % */ };
@@ -221,15 +230,25 @@ int  pt_comm_create_rank(pt_ctx* ctx, const void* id128, int rank, int world, pt
 int  pt_comm_reduce_image(pt_comm* comm, int root);
 void pt_comm_destroy(pt_comm* comm);
 
-/* ---- fast mode (NO reference counterpart, OUTSIDE the bit-exact contract, default off) ----
- * PT_TRAVERSAL_WIDE: inside an object the extend kernel walks a 4-wide collapse of the reference's binary BVH (each inner
- * child replaced by its two children: up to four boxes per fetch, about half the dependent fetches per ray).  The closest
- * hit is the same up to ties between equidistant triangles; visit order, visit counts and the low bits of hit_dist differ
- * (the reference carries hit_dist through its object-space round trips, which then happen at other moments), so path
- * state is no longer bit-comparable with the oracle: images agree statistically, sample counts exactly.  The reference-exact
- * buffers (pt_get_*) are unchanged; the collapse costs 128 B per triangle of extra device memory. */
-enum { PT_TRAVERSAL_REFERENCE = 0, PT_TRAVERSAL_WIDE = 1 };
+/* ---- tolerance mode (NO reference counterpart, default off) ----
+ * BASELINE.json north_star: "per-ray closest-hit triangle indices must be bit-exact, except for counted grazing/edge rays within
+ * 1e-6".  PT_TRAVERSAL_REFERENCE (default) is the bit-exact walk of scene.js:313-475.  PT_TRAVERSAL_WIDE uses that allowance:
+ * inside an object the extend kernel walks a compressed 4-wide collapse of the reference's binary BVH (each inner child replaced by
+ * its two children: up to four outward-rounded boxes per 64-B fetch, about half the dependent fetches per ray); triangles, the
+ * triangle test and the TLAS are the reference's.  The closest hit is the same except between triangles at (nearly) equal distance
+ * along the ray -- shared edges, grazing rays -- where the other visit order may keep the other one; the low bits of hit_dist differ
+ * too (the reference carries hit_dist through its object-space round trips, which then happen at other moments), so path state is no
+ * longer bit-comparable with the oracle: sample counts stay exact, images agree statistically.  The differing rays are COUNTED: one
+ * 64-ray block of every step's ray queue in `period` (pt_set_traversal_check; default 256, 1 = every ray, 0 = none; which blocks rotates
+ * with the step) is walked a second time with the reference walk, by extra workgroups of the next step's launch, and pt_run_stats reports how many of those returned another (hit_obj, hit_tri) and the
+ * largest relative hit_dist difference.  PT_TRAVERSAL_AUTO picks WIDE when the scene's binary nodes (64 B per packed triangle)
+ * exceed 256 MB -- they then no longer live in the caches and the walk is bound by dependent fetches -- and REFERENCE otherwise;
+ * pt_get_traversal_mode tells which walk the built scene uses.  The reference-exact buffers (pt_get_*) are unchanged; the collapse
+ * costs about 22 B per triangle of extra device memory.  Contexts made by pt_create_sharing_scene inherit mode and period. */
+enum { PT_TRAVERSAL_REFERENCE = 0, PT_TRAVERSAL_WIDE = 1, PT_TRAVERSAL_AUTO = 2 };
 int pt_set_traversal_mode(pt_ctx* ctx, int mode);
+int pt_get_traversal_mode(pt_ctx* ctx, int* mode_in_use);      /* PT_TRAVERSAL_REFERENCE or PT_TRAVERSAL_WIDE; needs a built scene */
+int pt_set_traversal_check(pt_ctx* ctx, int period);            /* takes effect when the next render starts (pt_render_init / pt_render_reset) */
 
 /* ---- measurement hooks (no reference counterpart; used by tools/ and bench.py only) ---- */
 /* The extend stage exists in several variants that differ in ray-to-lane mapping and stack placement, never in

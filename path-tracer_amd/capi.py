@@ -36,10 +36,12 @@ class PtStepStats(C.Structure):
 class PtRunStats(C.Structure):
     _fields_ = [("steps", C.c_int64), ("total_rays", C.c_int64), ("total_samples", C.c_int64),
                 ("stack_overflows", C.c_int64), ("extend_ms", C.c_double), ("extend_launches", C.c_int64),
-                ("traversal_bytes", C.c_int64), ("wasted_rays", C.c_int64)]
+                ("traversal_bytes", C.c_int64), ("wasted_rays", C.c_int64), ("checked_rays", C.c_int64),
+                ("mismatched_rays", C.c_int64), ("flipped_rays", C.c_int64), ("max_rel_dist_diff", C.c_double),
+                ("beyond_tolerance_rays", C.c_int64), ("lost_hit_rays", C.c_int64)]
 
 
-PT_TRAVERSAL_REFERENCE, PT_TRAVERSAL_WIDE = 0, 1
+PT_TRAVERSAL_REFERENCE, PT_TRAVERSAL_WIDE, PT_TRAVERSAL_AUTO = 0, 1, 2
 PT_TRACE_NOALLOC_MAX_RAYS = 4194304
 PT_MAT_LAMBERT, PT_MAT_EMITTER, PT_MAT_MIRROR, PT_MAT_GLOSSY, PT_MAX_EXT_MATERIALS = 0, 1, 2, 3, 14
 
@@ -94,6 +96,8 @@ SIGNATURES = {
     "pt_extend_variants": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]),
     "pt_set_extend_variant": (C.c_int, [C.c_void_p, C.c_int]),
     "pt_set_traversal_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "pt_get_traversal_mode": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "pt_set_traversal_check": (C.c_int, [C.c_void_p, C.c_int]),
     "pt_extend_replay": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "pt_extend_wave_log": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "pt_tonemap_rgba8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),

@@ -54,6 +54,7 @@ struct Mesh {
     int32_t* d_perm = nullptr;        // sorted position -> upload position
     int32_t* d_dfs = nullptr;         // inner node -> its number in depth-first preorder (traversal-order copy of the BLAS);
                                       // behind these n entries: PT_TOP_SLOTS + 1 ints, the nodes of the first levels by heap slot (k_dfs_index)
+    uint8_t* d_depth = nullptr;       // inner node -> links between it and the root (the even depths become the wide nodes of the tolerance mode)
     bool built = false, used = false; int64_t tri_offset = 0;
 };
 
@@ -84,7 +85,10 @@ struct pt_ctx {
     int64_t rays_cap = INT64_MAX;   // an upper bound of every coming step's queue length: the pool size, and once a header shows the
                                     // tickets used up, that header's queue length (retired slots never come back: the queue only shrinks)
     float4* d_ext_mats = nullptr; int n_ext_mats = 0;   // extension materials (pt_render_set_extensions)
-    float4* d_wide = nullptr; int traversal_mode = 0;   // fast mode (pt_set_traversal_mode): 4-wide collapse of the packed BLAS
+    float* d_chk_buf = nullptr; int32_t* d_chk_spill = nullptr; int chk_cap_alloc = 0;   // tolerance mode: side buffers of the exact re-walk (RenderConst::chk_*)
+    float4* d_wide = nullptr; float4* d_objects_wide = nullptr; int64_t n_wide = 0;   // tolerance mode: 4-wide collapse of the packed BLAS, objects that enter through it
+    int traversal_mode = 0;        // what pt_set_traversal_mode was given (PT_TRAVERSAL_AUTO included)
+    int check_period = 256;        // tolerance mode: one extend workgroup in check_period re-walks its rays exactly (pt_set_traversal_check)
     std::vector<std::pair<void*, size_t>> render_allocs; std::vector<hipEvent_t> events; int64_t ticket_begin = 0;
 };
 
@@ -156,25 +160,39 @@ int scene_stack_bound(pt_ctx* c) {
 // with 2 to 101 objects and, with the inner body's weight at 3 (scene_view), +2.5 % on a one-object scene (profiles/r02_sched_weight_sweep.txt).
 int extend_variant_of(const pt_ctx* c) { return c->extend_variant >= 0 ? c->extend_variant : 4; }
 
+// PT_TRAVERSAL_AUTO: the wide walk pays where the binary nodes do not stay in the caches -- they are 64 B per triangle, and the chip
+// has 8 x 4 MB of L2 in front of a 256 MB memory-side cache (measured, profiles/r03_mode_crossover.txt: 32 MB of nodes, 100 instances of
+// 500 k triangles, lose 20 % to the decode; 640 MB, the 10 M-triangle grid, gain).
+constexpr int64_t PT_AUTO_WIDE_NODE_BYTES = 256ll << 20;
+bool wide_wanted(const pt_ctx* c) {
+    return c->traversal_mode == PT_TRAVERSAL_WIDE || (c->traversal_mode == PT_TRAVERSAL_AUTO && c->n_tris * 64 > PT_AUTO_WIDE_NODE_BYTES);
+}
+bool wide_in_use(const pt_ctx* c) { return c->d_wide && wide_wanted(c); }
+
 SceneView scene_view(const pt_ctx* c) {
     SceneView v; v.nodes = c->d_blas_trav; v.objects = c->d_objects; v.tris = c->d_tri_records;
-    v.wide = c->traversal_mode == PT_TRAVERSAL_WIDE ? c->d_wide : nullptr;
+    v.wide = wide_in_use(c) ? c->d_wide : nullptr; v.objects_wide = v.wide ? c->d_objects_wide : nullptr;
     v.ext_mats = c->d_ext_mats; v.n_ext_mats = c->n_ext_mats; v.stack_bound = c->stack_bound;
     v.n_objects = c->n_objects; v.n_tris = (int32_t)std::min<int64_t>(c->n_tris, INT32_MAX);
     v.tlas_root = v.n_tris;
     v.sched_wi = c->n_objects > 1 ? 6 : 3; v.sched_wl = 9; v.sched_ws = 5;                   // profiles/r02_sched_weight_sweep.txt
+    v.sched_ww = 3;                                                                          // profiles/r03_wide_weight_sweep.txt
     static const struct EnvWeights {                                                         // measurement override: PT_SCHED_W="inner,triangle,switch"
-        int w[3] = {0, 0, 0};
-        EnvWeights() { const char* e = getenv("PT_SCHED_W"); if (!e || sscanf(e, "%d,%d,%d", &w[0], &w[1], &w[2]) != 3 || w[0] <= 0 || w[1] <= 0 || w[2] <= 0) w[0] = 0; }
+        int w[4] = {0, 0, 0, 0};
+        EnvWeights() {
+            const char* e = getenv("PT_SCHED_W"); int n = e ? sscanf(e, "%d,%d,%d,%d", &w[0], &w[1], &w[2], &w[3]) : 0;
+            if (n < 3 || w[0] <= 0 || w[1] <= 0 || w[2] <= 0) w[0] = 0;
+            if (n < 4 || w[3] <= 0) w[3] = 0;
+        }
     } env;
-    if (env.w[0] > 0) { v.sched_wi = env.w[0]; v.sched_wl = env.w[1]; v.sched_ws = env.w[2]; }
+    if (env.w[0] > 0) { v.sched_wi = env.w[0]; v.sched_wl = env.w[1]; v.sched_ws = env.w[2]; if (env.w[3] > 0) v.sched_ww = env.w[3]; }
     const bool top = c->d_objects_top && !v.wide;
     v.objects_top = top ? c->d_objects_top : nullptr; v.top_base = top ? v.n_tris + v.n_objects : INT32_MAX; v.top_nodes = top ? c->top_nodes : 0;
     return v;
 }
 
 // builders.js:174-192: sort -> radix tree -> up pass.  aabb: 2 quads per primitive.
-int build_bvh(pt_ctx* c, const float4* d_aabb, uint32_t* d_keys, int64_t n, int32_t* d_perm_out, float4* d_nodes_out, int32_t* d_dfs_out = nullptr) {
+int build_bvh(pt_ctx* c, const float4* d_aabb, uint32_t* d_keys, int64_t n, int32_t* d_perm_out, float4* d_nodes_out, int32_t* d_dfs_out = nullptr, uint8_t* d_depth_out = nullptr) {
     uint32_t* d_keys_sorted = nullptr; int32_t *d_parents = nullptr, *d_first = nullptr; char* d_tmp = nullptr; size_t tmp_bytes = 0;
     int rc = PT_OK; Tmp tmp;
     if ((rc = tmp.alloc(c, &d_keys_sorted, (size_t)n, false))) return rc;
@@ -189,7 +207,7 @@ int build_bvh(pt_ctx* c, const float4* d_aabb, uint32_t* d_keys, int64_t n, int3
     ptk_up_pass(d_perm_out, d_aabb, d_parents, n, d_nodes_out, c->stream);
     if (d_dfs_out) {
         HIPOK(c, hipMemsetAsync(d_dfs_out + n, 0xff, (PT_TOP_SLOTS + 1) * 4, c->stream));
-        ptk_dfs_index(d_parents, d_first, n, d_dfs_out, d_dfs_out + n, c->stream);
+        ptk_dfs_index(d_parents, d_first, n, d_dfs_out, d_dfs_out + n, d_depth_out, c->stream);
     }
     HIPOK(c, hipGetLastError());
     HIPOK(c, hipStreamSynchronize(c->stream));
@@ -199,15 +217,16 @@ int build_bvh(pt_ctx* c, const float4* d_aabb, uint32_t* d_keys, int64_t n, int3
 // builders.js:153-214 buildMeshBVH
 int build_mesh(pt_ctx* c, Mesh& m) {
     float4* d_aabb = nullptr; uint32_t* d_keys = nullptr; int rc; Tmp tmp;
-    dfree(m.d_nodes); dfree(m.d_tris_sorted); dfree(m.d_perm); dfree(m.d_dfs); m.d_nodes = m.d_tris_sorted = nullptr; m.d_perm = m.d_dfs = nullptr;   // a failed earlier attempt
+    dfree(m.d_nodes); dfree(m.d_tris_sorted); dfree(m.d_perm); dfree(m.d_dfs); dfree(m.d_depth); m.d_nodes = m.d_tris_sorted = nullptr; m.d_perm = m.d_dfs = nullptr; m.d_depth = nullptr;   // a failed earlier attempt
     if ((rc = tmp.alloc(c, &d_aabb, (size_t)m.n * 2, false))) return rc;
     if ((rc = tmp.alloc(c, &d_keys, (size_t)m.n, false))) return rc;
     if ((rc = dalloc(c, &m.d_nodes, (size_t)m.n * 4, false))) return rc;
     if ((rc = dalloc(c, &m.d_tris_sorted, (size_t)m.n * 3, false))) return rc;
     if ((rc = dalloc(c, &m.d_perm, (size_t)m.n, false))) return rc;
     if ((rc = dalloc(c, &m.d_dfs, (size_t)m.n + PT_TOP_SLOTS + 1, false))) return rc;
+    if ((rc = dalloc(c, &m.d_depth, (size_t)m.n, false))) return rc;
     ptk_tri_aabb_morton(m.d_tris_in, m.n, m.bounds, d_aabb, d_keys, c->stream);
-    if ((rc = build_bvh(c, d_aabb, d_keys, m.n, m.d_perm, m.d_nodes, m.d_dfs))) return rc;
+    if ((rc = build_bvh(c, d_aabb, d_keys, m.n, m.d_perm, m.d_nodes, m.d_dfs, m.d_depth))) return rc;
     ptk_rearrange(m.d_tris_in, m.d_perm, m.n, m.d_tris_sorted, c->stream);
     HIPOK(c, hipGetLastError());
     HIPOK(c, hipStreamSynchronize(c->stream));
@@ -217,12 +236,12 @@ int build_mesh(pt_ctx* c, Mesh& m) {
 
 void free_scene(pt_ctx* c) {
     if (c->scene_borrowed) {
-        c->d_wide = nullptr;
+        c->d_wide = c->d_objects_wide = nullptr; c->n_wide = 0;
         c->d_blas_nodes = c->d_blas_tris = c->d_tlas_nodes = c->d_objects = c->d_tri_records = c->d_blas_trav = nullptr; c->d_tlas_perm = nullptr; c->scene_built = false;
         c->d_objects_top = nullptr; c->top_nodes = 0;
         return;
     }
-    if (c->d_wide) { dfree(c->d_wide); c->d_wide = nullptr; }
+    dfree(c->d_wide); dfree(c->d_objects_wide); c->d_wide = c->d_objects_wide = nullptr; c->n_wide = 0;
     dfree(c->d_blas_nodes); dfree(c->d_blas_tris); dfree(c->d_tlas_nodes); dfree(c->d_objects); dfree(c->d_tlas_perm); dfree(c->d_tri_records); dfree(c->d_blas_trav);
     dfree(c->d_objects_top); c->d_objects_top = nullptr; c->top_nodes = 0;
     c->d_blas_nodes = c->d_blas_tris = c->d_tlas_nodes = c->d_objects = c->d_tri_records = c->d_blas_trav = nullptr; c->d_tlas_perm = nullptr; c->scene_built = false;
@@ -235,6 +254,7 @@ void free_render(pt_ctx* c) {
     c->events.clear();
     if (c->d_ext_mats) { dfree(c->d_ext_mats); c->d_ext_mats = nullptr; }
     c->n_ext_mats = 0;
+    dfree(c->d_chk_buf); dfree(c->d_chk_spill); c->d_chk_buf = nullptr; c->d_chk_spill = nullptr; c->chk_cap_alloc = 0;
     c->render_ready = false; c->d_image = nullptr;
 }
 
@@ -269,15 +289,42 @@ void enqueue_step(pt_ctx* c, int count_visits, hipEvent_t ev0, hipEvent_t ev1) {
     c->step++;
 }
 
-// fast mode: the 4-wide collapse of every used mesh's packed BVH (built on demand, dropped with the scene)
+// tolerance mode: the 4-wide collapse of every used mesh's packed BVH (built on demand, dropped with the scene) and the copy of
+// the objects whose roots point into it
 int build_wide(pt_ctx* c) {
     if (c->d_wide) return PT_OK;
-    int rc;
-    if ((rc = dalloc(c, &c->d_wide, (size_t)c->n_tris * PT_WIDE_QUADS, false))) return rc;
+    int rc; Tmp tmp;
+    // pass 1: which binary nodes become wide nodes, and their depth-first rank inside their mesh
+    std::vector<int32_t*> ranks; std::vector<int32_t> base; std::vector<int32_t> mesh_root, wide_root;
+    int64_t total = 0;
+    for (Mesh& m : c->meshes) {
+        if (!m.used) continue;
+        int32_t *d_rank = nullptr, *d_tiles = nullptr;
+        if ((rc = tmp.alloc(c, &d_rank, (size_t)m.n, false)) || (rc = tmp.alloc(c, &d_tiles, (size_t)((m.n + 1023) / 1024 + 2), false))) return rc;
+        const int64_t ntiles = (m.n + 1023) / 1024;
+        ptk_wide_flags(m.d_dfs, m.d_depth, m.n, d_rank, c->stream);
+        ptk_exclusive_scan(d_rank, m.n, d_tiles, d_tiles + ntiles, c->stream);
+        HIPOK(c, hipGetLastError());
+        int32_t count = 0;
+        if ((rc = read_back(c, &count, d_tiles + ntiles, 4))) return rc;
+        ranks.push_back(d_rank); base.push_back((int32_t)total);
+        mesh_root.push_back((int32_t)m.tri_offset); wide_root.push_back((int32_t)total);      // a mesh's root has rank 0
+        total += count;
+    }
+    if (total >= (1ll << 31)) return fail(c, PT_ERR_ARG, "tolerance mode: more than 2^31 wide nodes");
+    if ((rc = dalloc(c, &c->d_wide, (size_t)std::max<int64_t>(total, 1) * PT_WIDE_QUADS, false))) return rc;
+    if ((rc = dalloc(c, &c->d_objects_wide, (size_t)c->n_objects * 8, false))) return rc;
+    size_t u = 0;
     for (Mesh& m : c->meshes)
-        if (m.used) ptk_collapse_wide(c->d_blas_nodes, m.tri_offset, m.n, c->d_wide, c->stream);
+        if (m.used) { ptk_collapse_wide(c->d_blas_nodes, m.tri_offset, m.n, m.d_dfs, m.d_depth, ranks[u], base[u], c->d_wide, c->stream); u++; }
+    int32_t *d_mesh_root = nullptr, *d_wide_root = nullptr;
+    if ((rc = tmp.alloc(c, &d_mesh_root, mesh_root.size(), false)) || (rc = tmp.alloc(c, &d_wide_root, wide_root.size(), false))) return rc;
+    HIPOK(c, hipMemcpyAsync(d_mesh_root, mesh_root.data(), mesh_root.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPOK(c, hipMemcpyAsync(d_wide_root, wide_root.data(), wide_root.size() * 4, hipMemcpyHostToDevice, c->stream));
+    ptk_objects_top(c->d_objects, c->n_objects, d_mesh_root, d_wide_root, (int)mesh_root.size(), c->d_objects_wide, c->stream);
     HIPOK(c, hipGetLastError());
     HIPOK(c, hipStreamSynchronize(c->stream));
+    c->n_wide = total;
     return PT_OK;
 }
 
@@ -290,6 +337,18 @@ void note_header(pt_ctx* c, const StepHeader& h) {
 // fresh StepHeader: no step taken, ticket counter at this GPU's first ticket
 int write_header(pt_ctx* c) {
     HIPOK(c, hipStreamSynchronize(c->stream));
+    {   // tolerance mode: the re-walk period is fixed for the render that starts here
+        RenderConst& rc = c->rc;
+        rc.check_period = wide_in_use(c) ? c->check_period : 0;
+        rc.chk_cap = rc.check_period > 0 ? ((rc.num_paths + 63) / 64 + rc.check_period - 1) / rc.check_period : 0;
+        if (rc.chk_cap > c->chk_cap_alloc) {
+            dfree(c->d_chk_buf); dfree(c->d_chk_spill); c->d_chk_buf = nullptr; c->d_chk_spill = nullptr; c->chk_cap_alloc = 0;
+            int r;
+            if ((r = dalloc(c, &c->d_chk_buf, (size_t)2 * rc.chk_cap * 9 * 64, true)) || (r = dalloc(c, &c->d_chk_spill, (size_t)rc.chk_cap * 64 * PT_STACK_SIZE, false))) return r;
+            c->chk_cap_alloc = rc.chk_cap;
+        }
+        rc.chk_buf = c->d_chk_buf; rc.chk_spill = c->d_chk_spill;
+    }
     StepHeader h; memset(&h, 0, sizeof h);
     h.first_empty_step = -1; h.pixel_counter = c->ticket_begin; h.ticket_next[0] = c->ticket_begin;
     *c->h_hdr = h;
@@ -339,7 +398,7 @@ int pt_create_sharing_scene(pt_ctx* src, pt_ctx** out) {
     c->scene_borrowed = true; c->scene_built = true; c->extend_variant = src->extend_variant;
     c->n_tris = src->n_tris; c->n_objects = src->n_objects; c->n_meshes_used = src->n_meshes_used; c->stack_bound = src->stack_bound;
     c->d_blas_nodes = src->d_blas_nodes; c->d_blas_tris = src->d_blas_tris; c->d_tlas_nodes = src->d_tlas_nodes; c->d_objects = src->d_objects;
-    c->d_tlas_perm = src->d_tlas_perm; c->d_tri_records = src->d_tri_records; c->d_blas_trav = src->d_blas_trav; c->d_objects_top = src->d_objects_top; c->top_nodes = src->top_nodes; c->d_wide = src->d_wide; c->traversal_mode = src->traversal_mode;
+    c->d_tlas_perm = src->d_tlas_perm; c->d_tri_records = src->d_tri_records; c->d_blas_trav = src->d_blas_trav; c->d_objects_top = src->d_objects_top; c->top_nodes = src->top_nodes; c->d_wide = src->d_wide; c->d_objects_wide = src->d_objects_wide; c->n_wide = src->n_wide; c->traversal_mode = src->traversal_mode; c->check_period = src->check_period;
     c->lender = src; src->borrowers.push_back(c);
     return PT_OK;
 }
@@ -351,7 +410,7 @@ int pt_destroy(pt_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     free_render(c); free_scene(c);
-    for (Mesh& m : c->meshes) { dfree(m.d_tris_in); dfree(m.d_nodes); dfree(m.d_tris_sorted); dfree(m.d_perm); dfree(m.d_dfs); }
+    for (Mesh& m : c->meshes) { dfree(m.d_tris_in); dfree(m.d_nodes); dfree(m.d_tris_sorted); dfree(m.d_perm); dfree(m.d_dfs); dfree(m.d_depth); }
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return PT_OK;
@@ -483,17 +542,30 @@ int pt_scene_build(pt_ctx* c, const pt_instance* inst, int n_inst) {
     HIPOK(c, hipStreamSynchronize(c->stream));
     c->scene_built = true;
     if ((rc = scene_stack_bound(c))) return rc;
-    return c->traversal_mode == PT_TRAVERSAL_WIDE ? build_wide(c) : PT_OK;
+    return wide_wanted(c) ? build_wide(c) : PT_OK;
 }
 
 int pt_set_traversal_mode(pt_ctx* c, int mode) {
-    if (!c || (mode != PT_TRAVERSAL_REFERENCE && mode != PT_TRAVERSAL_WIDE)) return fail(c, PT_ERR_ARG, "pt_set_traversal_mode: unknown mode");
+    if (!c || (mode != PT_TRAVERSAL_REFERENCE && mode != PT_TRAVERSAL_WIDE && mode != PT_TRAVERSAL_AUTO)) return fail(c, PT_ERR_ARG, "pt_set_traversal_mode: unknown mode");
     if (c->scene_borrowed) return fail(c, PT_ERR_STATE, "pt_set_traversal_mode: this context borrows another context's scene (set the mode there first)");
     if (!c->borrowers.empty() && mode != c->traversal_mode) return fail(c, PT_ERR_STATE, "pt_set_traversal_mode: other contexts still borrow this context's scene; destroy them first");
     HIPOK(c, hipSetDevice(c->device));
     HIPOK(c, hipStreamSynchronize(c->stream));
     c->traversal_mode = mode;
-    return (mode == PT_TRAVERSAL_WIDE && c->scene_built) ? build_wide(c) : PT_OK;
+    return (c->scene_built && wide_wanted(c)) ? build_wide(c) : PT_OK;
+}
+
+int pt_get_traversal_mode(pt_ctx* c, int* mode_in_use) {
+    if (!c || !mode_in_use) return fail(c, PT_ERR_ARG, "pt_get_traversal_mode: null argument");
+    if (!c->scene_built) return fail(c, PT_ERR_STATE, "scene has not been built yet");
+    *mode_in_use = wide_in_use(c) ? PT_TRAVERSAL_WIDE : PT_TRAVERSAL_REFERENCE;
+    return PT_OK;
+}
+
+int pt_set_traversal_check(pt_ctx* c, int period) {
+    if (!c || period < 0 || period > (1 << 20)) return fail(c, PT_ERR_ARG, "pt_set_traversal_check: period must be in [0, 2^20]");
+    c->check_period = period;
+    return PT_OK;
 }
 
 int pt_scene_get_info(pt_ctx* c, pt_scene_info* out) {
@@ -793,6 +865,9 @@ int pt_render_run_many(pt_ctx** ctxs, int n, int64_t max_steps, int flags, pt_ru
             for (int sl = 0; sl < 64; sl++) for (int k = 0; k < 4; k++) v[k] += h.visits[sl][k];
             o->traversal_bytes = count ? (int64_t)(44 * h.total_rays + 64 * v[0] + 48 * v[1] + 128 * (v[2] + v[3])) : 0;
             o->wasted_rays = h.total_retired;
+            o->checked_rays = (int64_t)h.chk_rays; o->mismatched_rays = (int64_t)h.chk_mismatch; o->flipped_rays = (int64_t)h.chk_flips;
+            o->beyond_tolerance_rays = (int64_t)h.chk_beyond; o->lost_hit_rays = (int64_t)h.chk_lost;
+            { float f; memcpy(&f, &h.chk_max_rel_bits, 4); o->max_rel_dist_diff = f; }
         }
     }
     return PT_OK;

@@ -30,7 +30,9 @@ struct SceneView {
     const float4* tris;      // per triangle {v0, nx}{v1 - v0, ny}{v2 - v0, nz}: the reference's pt_triangle with what every ray
                              // would recompute from it -- the two edges (scene.js:479-481) and the unit normal
                              // (scene.js:233) -- evaluated once at build time by the same f32 operations (k_tri_records)
-    const float4* wide;      // fast mode only (pt_set_traversal_mode): compressed 4-wide collapse of the BLAS (PT_WIDE_QUADS per node), else null
+    const float4* wide;      // tolerance mode only (pt_set_traversal_mode): compressed 4-wide collapse of the BLAS (PT_WIDE_QUADS per node,
+                             // wide ids in depth-first order of the wide tree), else null
+    const float4* objects_wide;  // `objects` with every root replaced by the root of that mesh's wide tree (what a wide walk enters through)
     const float4* ext_mats;  // extension materials (pt_material = 2 quads each) for material ids 2.., null by default
     int32_t n_ext_mats;
     int32_t stack_bound;         // most stack entries any ray can hold in this scene (TLAS depth + deepest BLAS depth), or
@@ -38,6 +40,7 @@ struct SceneView {
     int32_t n_objects, n_tris;   // record counts of the four buffers (the extend kernel stages tiny scenes in LDS)
     int32_t tlas_root;           // = n_tris: the node id a walk starts at
     int32_t sched_wi, sched_wl, sched_ws;   // kind-scheduled walk: weights of the inner-node, triangle and switch bodies in the choice of a pass
+    int32_t sched_ww;                       // ... and of the 4-wide node body (tolerance mode)
     // Tree-top blocks (k_top_block): node ids top_base .. top_base + top_nodes - 1 of `nodes` hold the first levels of every mesh's
     // tree by heap slot; objects_top = `objects` with the roots pointing there.  A launch that stages them in LDS walks from
     // objects_top; every other launch walks from `objects` and never sees them.  top_nodes = 0: the scene has none.
@@ -89,6 +92,12 @@ struct StepHeader {
     // count (the longest lane's) per ray class, the scan of the next step puts the class that held the longest wave first.
     uint32_t cls_max[32][2];             // {camera, bounce} maximum trips of a wave, spread over 32 cells
     int32_t  extend_order, pad2;         // 0 = camera rays first (queue order), 1 = bounce rays first
+    // Tolerance mode (PT_TRAVERSAL_WIDE): the sampled workgroups of an extend launch walk their rays a second time, exactly as the
+    // reference does, and add up how the two walks differ (RenderConst::check_period; pt_run_stats).
+    unsigned long long chk_rays, chk_mismatch, chk_flips;   // rays walked twice; with another (hit_obj, hit_tri); of those, hit against miss
+    unsigned long long chk_beyond, chk_lost;                // hit_dist apart by more than 1e-6 relative (flips included); of those, the wide walk's hit is the farther one (or a miss)
+    uint32_t chk_max_rel_bits; int32_t prev_n_rays;   // prev_n_rays: n_rays of the step before (the rays the front workgroups re-walk)
+    //     // largest |hit_dist(wide) - hit_dist(exact)| / hit_dist(exact) over the rays both walks hit (f32 bits; atomicMax)
 };
 
 struct CameraFrame { float fwd[3], right[3], up[3], fov_sin, aspect; };   // camera.js:96-111, evaluated once per render on the device
@@ -99,6 +108,11 @@ struct RenderConst {
     CameraFrame frame;
     int32_t max_nb;      // logic.js:111 constant (20) unless the max_nb extension is set
     uint32_t seed_mix;   // 0 unless the seed extension is set
+    // tolerance mode: the rays of one queue block in check_period are walked a second time, exactly (0 = none, 1 = all), by chk_cap
+    // workgroups in front of the next step's extend launch; chk_buf: 2 x chk_cap x 9 x 64 words (ray, hit of the wide walk), chk_spill: those
+    // workgroups' share of the traversal-stack spill.  Fixed for a render (set when it starts).
+    int32_t check_period, chk_cap;
+    float* chk_buf; int32_t* chk_spill;
 };
 
 // ---- launchers (pt_kernels_build.hip) ---------------------------------------------------------
@@ -106,7 +120,8 @@ void ptk_tri_aabb_morton(const float4* tris, int64_t n, const float bounds[6], f
 void ptk_obj_morton(const float4* aabb, int64_t n, const float bounds[6], uint32_t* keys, hipStream_t s);
 void ptk_radix_tree(const uint32_t* sorted_keys, int64_t n, int32_t* parents /* 2n, zeroed */, int32_t* first /* n or null */, hipStream_t s);
 // traversal-order (depth-first preorder) numbering of a tree's inner nodes and the reordered copy of a packed mesh's nodes
-void ptk_dfs_index(const int32_t* parents, const int32_t* first, int64_t n, int32_t* dfs /* n */, int32_t* top_nodes /* PT_TOP_SLOTS, preset to -1, or null */, hipStream_t s);
+void ptk_dfs_index(const int32_t* parents, const int32_t* first, int64_t n, int32_t* dfs /* n */, int32_t* top_nodes /* PT_TOP_SLOTS, preset to -1, or null */,
+                   uint8_t* depth /* n: links between node and root, or null */, hipStream_t s);
 void ptk_top_block(const float4* packed_nodes, const int32_t* dfs, const int32_t* top_nodes, int64_t offset, int64_t n, int levels, int top_id, float4* trav_nodes, hipStream_t s);
 void ptk_tlas_rebase(const float4* tlas_nodes, int n, int delta, float4* out /* the TLAS part of SceneView::nodes */, hipStream_t s);
 void ptk_objects_top(const float4* objects, int n, const int32_t* mesh_root, const int32_t* top_root, int n_meshes, float4* out, hipStream_t s);
@@ -115,17 +130,25 @@ void ptk_up_pass(const int32_t* idx, const float4* aabb, const int32_t* parents,
 void ptk_rearrange(const float4* tris_in, const int32_t* idx, int64_t n, float4* tris_out, hipStream_t s);
 void ptk_tri_records(const float4* tris, int64_t n, float4* records, hipStream_t s);   // SceneView::tris from pt_triangle[n]
 void ptk_pack_mesh(const float4* src_nodes, const float4* src_tris, int64_t n, int32_t offset, float4* dst_nodes, float4* dst_tris, hipStream_t s);
-// Fast mode (outside the bit-exact contract): wide[node] = the binary node `node` with each inner child
-// replaced by that child's two children -- up to four boxes per fetch -- and the boxes quantised to 8 bits per coordinate
-// in a frame slightly larger than their union, rounded outwards (a compressed wide BVH): the traversal is bound by the
-// number of 16-B lane requests it sends to L1, and this node is 4 quads for four children instead of 4 quads for two.
+// Tolerance mode (north_star: hit indices exact "except for counted grazing/edge rays within 1e-6"): a wide node = a
+// binary node at an even depth of its mesh's tree with each inner child replaced by that child's two children -- up to four boxes per
+// fetch -- and the boxes quantised to 8 bits per coordinate in a frame slightly larger than their union, rounded outwards (a compressed
+// wide BVH): the traversal is bound by the number of dependent fetches and of 16-B lane requests it sends to L1, and this node is 4 quads
+// for four children instead of 4 quads for two.  Wide nodes are numbered in depth-first order of the wide tree, the meshes one after the
+// other (ptk_wide_count gives a mesh's count; only the binary nodes at even depths have one, a third of the triangle count).
 //   quad 0: frame origin x, y, z (f32) | biased exponents of the three power-of-two steps, one byte each
 //   quad 1: child ref[4] (>= 0 wide node, < 0 triangle leaf, PT_WIDE_EMPTY = unused slot)
 //   quad 2: lo.x[4] | lo.y[4] | lo.z[4] | hi.x[4]   (one byte per child)        quad 3: hi.y[4] | hi.z[4] | 0 | 0
 // child box = origin + q * step.
 #define PT_WIDE_EMPTY 0x7fffffff
 #define PT_WIDE_QUADS 4
-void ptk_collapse_wide(const float4* blas_nodes, int64_t offset, int64_t n, float4* wide, hipStream_t s);
+// flags[dfs[i]] = 1 for the binary nodes i of one mesh that become wide nodes; scan = exclusive prefix sum of flags in place, *total = their
+// number (three launches; tile_sums: (n + 1023) / 1024 + 1 ints).
+void ptk_wide_flags(const int32_t* dfs, const uint8_t* depth, int64_t n, int32_t* flags, hipStream_t s);
+void ptk_exclusive_scan(int32_t* data, int64_t n, int32_t* tile_sums, int32_t* total, hipStream_t s);
+// one packed mesh (binary nodes [offset, offset + n) of blas_nodes) -> its wide nodes at wide ids wide_base + rank[dfs[i]]
+void ptk_collapse_wide(const float4* blas_nodes, int64_t offset, int64_t n, const int32_t* dfs, const uint8_t* depth, const int32_t* rank,
+                       int32_t wide_base, float4* wide, hipStream_t s);
 void ptk_pack_objects(const void* instances /* pt_instance[n] */, const int32_t* tlas_perm, const int32_t* mesh_tri_offset,
                       int n, float4* objects, hipStream_t s);
 // pt_sort.hip: stable LSD radix sort of u32 keys; vout[i] = original position of the key that lands at i; kin is left alone.

@@ -207,11 +207,11 @@ void ptk_radix_tree(const uint32_t* keys, int64_t n, int32_t* parents, int32_t* 
 // top_nodes (PT_TOP_SLOTS ints, preset to -1): the inner nodes of the first PT_TOP_LEVELS levels by heap slot -- root = 0, the
 // children of slot s = 2s + 1 (left), 2s + 2 (right) -- for the tree-top block of the traversal copy (k_top_block).
 __global__ __launch_bounds__(PT_BLOCK) void k_dfs_index(const int32_t* __restrict__ parents, const int32_t* __restrict__ first, int n, int32_t* __restrict__ dfs,
-                                                        int32_t* __restrict__ top_nodes) {
+                                                        int32_t* __restrict__ top_nodes, uint8_t* __restrict__ depth_out) {
     int i = blockIdx.x * PT_BLOCK + threadIdx.x;
     if (i >= n) return;
     if (i == 0 && top_nodes) top_nodes[0] = 0;              // the root (also of the one-leaf tree)
-    if (i >= n - 1) { dfs[i] = i; return; }                 // the unused tail record of an n-leaf tree (and the whole one-leaf tree) stays put
+    if (i >= n - 1) { dfs[i] = i; if (depth_out) depth_out[i] = 0; return; }   // the unused tail record of an n-leaf tree (and the whole one-leaf tree) stays put
     int cnt = 0, depth = 0; unsigned path = 0u;             // path: bit j = the side taken j links above i (1 = right)
     for (int p = i, guard = 0; p != 0 && guard < 64; guard++) {
         int link = parents[p]; cnt += (link & 1) == 0;
@@ -219,6 +219,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_dfs_index(const int32_t* __restric
         depth++; p = link >> 1;
     }
     dfs[i] = first[i] + cnt;
+    if (depth_out) depth_out[i] = (uint8_t)depth;            // <= 62 links (32 key bits + 30 index bits)
     if (top_nodes && depth > 0 && depth < PT_TOP_LEVELS) top_nodes[(1 << depth) - 1 + (int)path] = i;
 }
 // The tree-top block of one packed mesh: the nodes of its first `levels` levels, by heap slot, at node ids top_id .. of `trav`
@@ -282,8 +283,8 @@ __global__ __launch_bounds__(PT_BLOCK) void k_reorder_nodes(const float4* __rest
     float4* dst = trav + 4 * (offset + dfs[i]);
     dst[0] = q0; dst[1] = q1; dst[2] = q2; dst[3] = q3;
 }
-void ptk_dfs_index(const int32_t* parents, const int32_t* first, int64_t n, int32_t* dfs, int32_t* top_nodes, hipStream_t s) {
-    hipLaunchKernelGGL(k_dfs_index, grid_for(n), dim3(PT_BLOCK), 0, s, parents, first, (int)n, dfs, top_nodes);
+void ptk_dfs_index(const int32_t* parents, const int32_t* first, int64_t n, int32_t* dfs, int32_t* top_nodes, uint8_t* depth, hipStream_t s) {
+    hipLaunchKernelGGL(k_dfs_index, grid_for(n), dim3(PT_BLOCK), 0, s, parents, first, (int)n, dfs, top_nodes, depth);
 }
 void ptk_top_block(const float4* packed, const int32_t* dfs, const int32_t* top_nodes, int64_t offset, int64_t n, int levels, int top_id, float4* trav, hipStream_t s) {
     hipLaunchKernelGGL(k_top_block, dim3(1), dim3(PT_TOP_SLOTS + 1), 0, s, packed, dfs, top_nodes, offset, (int)n, levels, top_id, trav);
@@ -319,19 +320,84 @@ void ptk_tri_records(const float4* tris, int64_t n, float4* records, hipStream_t
 void ptk_pack_mesh(const float4* src_nodes, const float4* src_tris, int64_t n, int32_t offset, float4* dst_nodes, float4* dst_tris, hipStream_t s) {
     hipLaunchKernelGGL(k_pack_mesh, grid_for(n), dim3(PT_BLOCK), 0, s, src_nodes, src_tris, n, offset, dst_nodes, dst_tris);
 }
-// ---- fast mode: 4-wide collapse of one packed mesh (nodes [offset, offset + n), inner nodes offset .. offset + n - 2) ----
-__global__ __launch_bounds__(PT_BLOCK) void k_collapse_wide(const float4* __restrict__ bin, int64_t offset, int64_t n, float4* __restrict__ wide) {
+// ---- tolerance mode: 4-wide collapse of one packed mesh (binary nodes [offset, offset + n), inner nodes offset .. offset + n - 2) ----
+// The binary nodes at even depths become the wide nodes.  They are numbered in depth-first order of the wide tree, which is the
+// binary tree's preorder with the odd levels left out: flags[dfs[i]] = 1 for an even-depth node i, rank = exclusive prefix sum.
+// A wide subtree is one contiguous block and a node's first inner child is the next record (two 64-B nodes share a 128-B line).
+__global__ __launch_bounds__(PT_BLOCK) void k_wide_flags(const int32_t* __restrict__ dfs, const uint8_t* __restrict__ depth, int n, int32_t* __restrict__ flags) {
+    int i = blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const bool real = i < n - 1 || n == 1;                  // node n-1 is the unused tail slot of an n-leaf radix tree
+    flags[dfs[i]] = (real && (depth[i] & 1) == 0) ? 1 : 0;  // dfs is a permutation of [0, n): every flag is written
+}
+// exclusive scan of int32, 1024 per tile: tile sums -> their scan by one workgroup -> added back
+__global__ __launch_bounds__(256) void k_scan_tiles(int32_t* __restrict__ data, int n, int32_t* __restrict__ tile_sums) {
+    __shared__ int s_wave[4];
+    const int base = blockIdx.x * 1024 + threadIdx.x * 4, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int v[4], sum = 0;
+    for (int k = 0; k < 4; k++) { v[k] = base + k < n ? data[base + k] : 0; sum += v[k]; }
+    int incl = sum;
+    for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int front = 0;
+    for (int w = 0; w < wave; w++) front += s_wave[w];
+    int run = front + incl - sum;
+    for (int k = 0; k < 4; k++) { if (base + k < n) data[base + k] = run; run += v[k]; }
+    if (threadIdx.x == 255) tile_sums[blockIdx.x] = front + incl;
+}
+__global__ __launch_bounds__(1024) void k_scan_tops(int32_t* __restrict__ tile_sums, int ntiles, int32_t* __restrict__ total) {
+    __shared__ int s_wave[16]; __shared__ int s_carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int start = 0; start < ntiles; start += 1024) {
+        const int i = start + threadIdx.x, v = i < ntiles ? tile_sums[i] : 0;
+        int incl = v;
+        for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        int front = s_carry;
+        for (int w = 0; w < wave; w++) front += s_wave[w];
+        if (i < ntiles) tile_sums[i] = front + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = front + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = s_carry;
+}
+__global__ __launch_bounds__(256) void k_scan_add(int32_t* __restrict__ data, int n, const int32_t* __restrict__ tile_sums) {
+    const int base = blockIdx.x * 1024 + threadIdx.x * 4, add = tile_sums[blockIdx.x];
+    for (int k = 0; k < 4; k++) if (base + k < n) data[base + k] += add;
+}
+void ptk_wide_flags(const int32_t* dfs, const uint8_t* depth, int64_t n, int32_t* flags, hipStream_t s) {
+    hipLaunchKernelGGL(k_wide_flags, grid_for(n), dim3(PT_BLOCK), 0, s, dfs, depth, (int)n, flags);
+}
+void ptk_exclusive_scan(int32_t* data, int64_t n, int32_t* tile_sums, int32_t* total, hipStream_t s) {
+    const int ntiles = (int)((n + 1023) / 1024);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(256), 0, s, data, (int)n, tile_sums);
+    hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(1024), 0, s, tile_sums, ntiles, total);
+    hipLaunchKernelGGL(k_scan_add, dim3(ntiles), dim3(256), 0, s, data, (int)n, tile_sums);
+}
+__global__ __launch_bounds__(PT_BLOCK) void k_collapse_wide(const float4* __restrict__ bin, int64_t offset, int64_t n, const int32_t* __restrict__ dfs,
+                                                            const uint8_t* __restrict__ depth, const int32_t* __restrict__ rank, int32_t wide_base,
+                                                            float4* __restrict__ wide) {
     int64_t i = (int64_t)blockIdx.x * PT_BLOCK + threadIdx.x;
     if (i >= n) return;
+    if (!(i < n - 1 || n == 1) || (depth[i] & 1)) return;
     float lo[4][3], hi[4][3]; int ref[4]; int k = 0;
     for (int s = 0; s < 4; s++) { ref[s] = PT_WIDE_EMPTY; for (int a = 0; a < 3; a++) lo[s][a] = hi[s][a] = 0.0f; }
-    auto slot = [&](int c, float4 mn, float4 mx) { ref[k] = c; lo[k][0] = mn.x; lo[k][1] = mn.y; lo[k][2] = mn.z; hi[k][0] = mx.x; hi[k][1] = mx.y; hi[k][2] = mx.z; k++; };
+    // a grandchild that is an inner node sits at an even depth again: its reference is its wide id
+    auto slot = [&](int c, float4 mn, float4 mx) {
+        ref[k] = c < 0 ? c : wide_base + rank[dfs[c - (int)offset]];
+        lo[k][0] = mn.x; lo[k][1] = mn.y; lo[k][2] = mn.z; hi[k][0] = mx.x; hi[k][1] = mx.y; hi[k][2] = mx.z; k++;
+    };
     auto child = [&](int c, float4 mn, float4 mx) {
         if (c >= 0) { const float4* cn = bin + 4 * (int64_t)c; float4 c0 = cn[0], c1 = cn[1], c2 = cn[2], c3 = cn[3];
                       slot(__float_as_int(c0.w), c0, c1); slot(__float_as_int(c2.w), c2, c3); }
         else slot(c, mn, mx);
     };
-    if (i < n - 1 || n == 1) {                      // node n-1 is the unused tail slot of an n-leaf radix tree
+    {
         const float4* nd = bin + 4 * (offset + i);
         float4 a0 = nd[0], a1 = nd[1], a2 = nd[2], a3 = nd[3];
         child(__float_as_int(a0.w), a0, a1);
@@ -358,14 +424,15 @@ __global__ __launch_bounds__(PT_BLOCK) void k_collapse_wide(const float4* __rest
             qlo[a] |= (unsigned)l << (8 * c); qhi[a] |= (unsigned)h << (8 * c);
         }
     }
-    float4* w = wide + PT_WIDE_QUADS * (offset + i);
+    float4* w = wide + PT_WIDE_QUADS * (int64_t)(wide_base + rank[dfs[i]]);
     w[0] = make_float4(org[0], org[1], org[2], __uint_as_float(ebits));
     w[1] = make_float4(__int_as_float(ref[0]), __int_as_float(ref[1]), __int_as_float(ref[2]), __int_as_float(ref[3]));
     w[2] = make_float4(__uint_as_float(qlo[0]), __uint_as_float(qlo[1]), __uint_as_float(qlo[2]), __uint_as_float(qhi[0]));
     w[3] = make_float4(__uint_as_float(qhi[1]), __uint_as_float(qhi[2]), 0.0f, 0.0f);
 }
-void ptk_collapse_wide(const float4* blas_nodes, int64_t offset, int64_t n, float4* wide, hipStream_t s) {
-    hipLaunchKernelGGL(k_collapse_wide, grid_for(n), dim3(PT_BLOCK), 0, s, blas_nodes, offset, n, wide);
+void ptk_collapse_wide(const float4* blas_nodes, int64_t offset, int64_t n, const int32_t* dfs, const uint8_t* depth, const int32_t* rank,
+                       int32_t wide_base, float4* wide, hipStream_t s) {
+    hipLaunchKernelGGL(k_collapse_wide, grid_for(n), dim3(PT_BLOCK), 0, s, blas_nodes, offset, n, dfs, depth, rank, wide_base, wide);
 }
 void ptk_pack_objects(const void* instances, const int32_t* perm, const int32_t* mesh_tri_offset, int n, float4* objects, hipStream_t s) {
     hipLaunchKernelGGL(k_pack_objects, grid_for(n), dim3(PT_BLOCK), 0, s, (const float*)instances, perm, mesh_tri_offset, n, objects);

@@ -88,14 +88,14 @@ __device__ __forceinline__ void switch_space(float4 r0, float4 r1, float4 r2, Ra
 }
 
 // One trip through the reference's while loop (scene.js:328-440).  Returns false when the loop ends.
-// fast mode: order two (distance, child) pairs, nearer first
+// tolerance mode: order two (distance, child) pairs, nearer first
 __device__ __forceinline__ void near_first(float& ka, int& ra, float& kb, int& rb) {
     bool sw = kb < ka;
     float k = sw ? kb : ka; int rr = sw ? rb : ra;
     kb = sw ? ka : kb; rb = sw ? ra : rb; ka = k; ra = rr;
 }
 
-// WIDE (fast mode): inside an object the nodes are the compressed 4-wide collapse (SceneView::wide, layout in
+// WIDE (tolerance mode): inside an object the nodes are the compressed 4-wide collapse (SceneView::wide, layout in
 // pt_internal.h): one 64-B fetch tests up to four (outward-rounded) boxes, the nearest valid child is taken and the others
 // are pushed farthest first.  Same closest hit up to ties;
 // visit order, visit counts and the low bits of hit_dist differ from the reference's (hit_dist is carried through the
@@ -113,7 +113,7 @@ __device__ __forceinline__ bool trav_step(const SceneView& sc, Ray& r, const STK
     if (r.node < 0) {
         if (r.obj < 0) {                                        // :357-379 entering an object
             r.obj = -(r.node + 1);
-            const float4* ob = sc.objects + 8 * (int64_t)r.obj;
+            const float4* ob = (WIDE ? sc.objects_wide : sc.objects) + 8 * (int64_t)r.obj;
             r.node = __float_as_int(ob[3].x); r.switch_pt = r.sp;
             switch_space(ob[4], ob[5], ob[6], r);
             if (COUNT) r.n_enter++;
@@ -125,7 +125,7 @@ __device__ __forceinline__ bool trav_step(const SceneView& sc, Ray& r, const STK
             if (COUNT) r.n_leaf++;
             r.sp -= 1; r.node = stk.get(r.sp);
         }
-    } else if (WIDE && r.obj >= 0) {                            // fast mode: 4-wide BLAS node
+    } else if (WIDE && r.obj >= 0) {                            // tolerance mode: 4-wide BLAS node
         const float4* nd = sc.wide + PT_WIDE_QUADS * (int64_t)r.node;
         float4 h = nd[0], rf = nd[1], qa = nd[2], qb = nd[3];
         if (COUNT) r.n_inner++;                                 // one 64-B record
@@ -192,11 +192,15 @@ __device__ __forceinline__ bool trav_step(const SceneView& sc, Ray& r, const STK
 // What it does buy is fewer waits (SQ_WAIT_ANY -14 %): in the full render it is +3...8 % on scenes with several objects and -12 %
 // on the one-object grid, so the library picks it only for scenes with more than one object (pt_api.hip).
 // --------------------------------------------------------------------------------------------
-enum { PT_K_INNER = 0, PT_K_LEAF = 1, PT_K_SWITCH = 2, PT_K_DONE = 3 };
+// (The tolerance-mode kernels need 65-72 registers, 7 waves per SIMD.  Capped at 64 for 8 waves they spill two registers inside the
+// outer loop and lose 11 %: profiles/r03_wide_occupancy_ab.txt.)
+enum { PT_K_INNER = 0, PT_K_LEAF = 1, PT_K_SWITCH = 2, PT_K_DONE = 3, PT_K_WIDE = 4 };
 // the weights of the three bodies in the choice of the next pass are per scene: SceneView::sched_wi / wl / ws
+// WIDE (tolerance mode): a node id >= 0 inside an object names a 4-wide node (SceneView::wide); in the TLAS it is a binary node as ever
+template <bool WIDE = false>
 __device__ __forceinline__ int kind_after(const Ray& r) {
     // three selects, no branches (the exec-mask bookkeeping of nested ifs costs the shared scalar unit more than the selects cost a SIMD)
-    int k = r.node >= 0 ? PT_K_INNER : (r.obj < 0 ? PT_K_SWITCH : PT_K_LEAF);   // :357 enter / :380 triangle
+    int k = r.node >= 0 ? ((WIDE && r.obj >= 0) ? PT_K_WIDE : PT_K_INNER) : (r.obj < 0 ? PT_K_SWITCH : PT_K_LEAF);   // :357 enter / :380 triangle
     k = r.sp < r.switch_pt ? PT_K_SWITCH : k;                  // :330 the next trip begins by leaving the object
     return r.sp < 0 ? PT_K_DONE : k;                           // the loop condition (scene.js:328)
 }
@@ -212,7 +216,7 @@ __device__ __forceinline__ bool trip_guard(Ray& r) {
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef const volatile __attribute__((address_space(3))) v4f* LdsQuads;   // typed as LDS, and volatile, so that the two fetch paths below stay two
                                                                           // (the compiler otherwise merges them into flat loads through a select of addresses)
-template <bool COUNT, class STK, bool TOP = false>
+template <bool COUNT, class STK, bool TOP = false, bool WIDE = false>
 __device__ __forceinline__ int op_inner(const SceneView& sc, Ray& r, const STK& stk, LdsQuads lds = nullptr) {      // :392-439
     // One exit: a lane stopped by a guard runs the visit like the others (it changes no hit; its stack slot and node are its own and
     // never read again) and is retired at the end.  Early returns here cost every lane of every pass a dozen register copies.
@@ -249,9 +253,57 @@ __device__ __forceinline__ int op_inner(const SceneView& sc, Ray& r, const STK& 
     // LDS -- was measured: -1 %, profiles/r02_instruction_cuts.txt)
     if (!(l_valid || r_valid)) { r.sp -= 1; r.node = stk.get(r.sp); }
     if (!STK::shallow) r.overflow |= (stop || full) ? 1 : 0;
-    return (stop || full) ? PT_K_DONE : kind_after(r);
+    return (stop || full) ? PT_K_DONE : kind_after<WIDE>(r);
 }
+// Tolerance mode: one 64-B record holds up to four quantised child boxes (pt_internal.h).  The nearest valid child is taken, the others
+// are pushed farthest first.  One exit, like op_inner.  Written for instruction count (the body is VALU work between two dependent
+// fetches): the ray is brought into the node's frame once -- t = (org + q * step - o) * id = q * (step * id) + (org - o) * id, a plane
+// costs one byte-to-float convert and one fma -- the near and far plane words of an axis are chosen once per node by the sign of the
+// direction, and the four validity tests are selects, not branches.  (The boxes are rounded outwards with a pad of >= 2e-6 of the
+// coordinate and 0.2 % of the frame, which covers what this rounding moves; a plane that comes out NaN -- a direction component of
+// exactly 0 -- is skipped by min3 / max3, which can only widen the box.)
+__device__ __forceinline__ float ubyte_f32(unsigned w, int c) { return (float)((w >> (8 * c)) & 0xffu); }     // v_cvt_f32_ubyte<c>
+__device__ __forceinline__ float fmax3_(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float fmin3_(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 template <bool COUNT, class STK>
+__device__ __forceinline__ int op_wide(const SceneView& sc, Ray& r, const STK& stk) {
+    r.iter++;
+    const bool stop = !STK::shallow && r.iter > PT_MAX_ITERS;
+    const float4* nd = sc.wide + PT_WIDE_QUADS * (int64_t)r.node;
+    const float4 h = nd[0], rf = nd[1], qa = nd[2], qb = nd[3];
+    if (COUNT) r.n_inner += stop ? 0 : 1;                       // one 64-B record
+    const unsigned eb = __float_as_uint(h.w);
+    const f3 st = F3(__uint_as_float((eb & 0xffu) << 23), __uint_as_float(((eb >> 8) & 0xffu) << 23), __uint_as_float(((eb >> 16) & 0xffu) << 23));
+    const f3 a = st * r.id, b = (F3(h) - r.o) * r.id;
+    const unsigned lx = __float_as_uint(qa.x), ly = __float_as_uint(qa.y), lz = __float_as_uint(qa.z), hx = __float_as_uint(qa.w),
+                   hy = __float_as_uint(qb.x), hz = __float_as_uint(qb.y);
+    const bool bx = r.id.x < 0.0f, by = r.id.y < 0.0f, bz = r.id.z < 0.0f;
+    const unsigned nx = bx ? hx : lx, fx = bx ? lx : hx, ny = by ? hy : ly, fy = by ? ly : hy, nz = bz ? hz : lz, fz = bz ? lz : hz;
+    int r0 = __float_as_int(rf.x), r1 = __float_as_int(rf.y), r2 = __float_as_int(rf.z), r3 = __float_as_int(rf.w);
+    const float INF = __builtin_inff(), lim = r.hit_dist;
+#define PT_CHILD_T(c, ref)                                                                                                             \
+    [&]() -> float {                                                                                                                   \
+        const float tn = fmax3_(__builtin_fmaf(ubyte_f32(nx, c), a.x, b.x), __builtin_fmaf(ubyte_f32(ny, c), a.y, b.y), __builtin_fmaf(ubyte_f32(nz, c), a.z, b.z)); \
+        const float tf = fmin3_(__builtin_fmaf(ubyte_f32(fx, c), a.x, b.x), __builtin_fmaf(ubyte_f32(fy, c), a.y, b.y), __builtin_fmaf(ubyte_f32(fz, c), a.z, b.z)); \
+        const bool ok = (fmax_(tn, 0.0f) <= tf) & (tn < lim) & ((ref) != PT_WIDE_EMPTY);                                                \
+        return ok ? tn : INF;                                                                                                          \
+    }()
+    float k0 = PT_CHILD_T(0, r0), k1 = PT_CHILD_T(1, r1), k2 = PT_CHILD_T(2, r2), k3 = PT_CHILD_T(3, r3);
+#undef PT_CHILD_T
+    near_first(k0, r0, k1, r1); near_first(k2, r2, k3, r3); near_first(k0, r0, k2, r2); near_first(k1, r1, k3, r3); near_first(k1, r1, k2, r2);
+    const int nv = (k0 != INF) + (k1 != INF) + (k2 != INF) + (k3 != INF);
+    const bool full = !STK::shallow && r.sp + nv - 1 > PT_STACK_SIZE;        // pushes onto a full stack end the ray
+    if (!full) {
+        if (nv > 3) { stk.put(r.sp, r3); r.sp += 1; }
+        if (nv > 2) { stk.put(r.sp, r2); r.sp += 1; }
+        if (nv > 1) { stk.put(r.sp, r1); r.sp += 1; }
+    }
+    r.node = r0;
+    if (nv == 0) { r.sp -= 1; r.node = stk.get(r.sp); }
+    if (!STK::shallow) r.overflow |= (stop || full) ? 1 : 0;
+    return (stop || full) ? PT_K_DONE : kind_after<true>(r);
+}
+template <bool COUNT, class STK, bool WIDE = false>
 __device__ __forceinline__ int op_leaf(const SceneView& sc, Ray& r, const STK& stk) {       // :380-391
     r.iter++;
     const bool stop = !STK::shallow && r.iter > PT_MAX_ITERS;                // as in op_inner: one exit; a stopped lane's test changes nothing
@@ -262,21 +314,21 @@ __device__ __forceinline__ int op_leaf(const SceneView& sc, Ray& r, const STK& s
     if (COUNT) r.n_leaf += stop ? 0 : 1;
     r.sp -= 1; r.node = stk.get(r.sp);
     if (!STK::shallow) r.overflow |= stop ? 1 : 0;
-    return stop ? PT_K_DONE : kind_after(r);
+    return stop ? PT_K_DONE : kind_after<WIDE>(r);
 }
 // leaving (:330-355, rows 0-2 of the object = localToWorld) and entering (:357-379, rows 4-6 = worldToLocal, row 3 = root and
 // material) run the same arithmetic on different rows: one body serves both groups of lanes
-template <bool COUNT, class STK>
+template <bool COUNT, class STK, bool WIDE = false>
 __device__ __forceinline__ int op_switch(const SceneView& sc, Ray& r) {
     const bool entering = r.obj < 0;
     if (entering && !trip_guard<STK>(r)) return PT_K_DONE;
     const int oi = entering ? -(r.node + 1) : r.obj;
-    const float4* ob = sc.objects + 8 * (int64_t)oi + (entering ? 4 : 0);
+    const float4* ob = (WIDE ? sc.objects_wide : sc.objects) + 8 * (int64_t)oi + (entering ? 4 : 0);
     float4 r0 = ob[0], r1 = ob[1], r2 = ob[2];
     if (entering) { r.node = __float_as_int(ob[-1].x); r.switch_pt = r.sp; r.obj = oi; if (COUNT) r.n_enter++; }
     else { r.switch_pt = -1; r.obj = -1; if (COUNT) r.n_leave++; }
     switch_space(r0, r1, r2, r);
-    return kind_after(r);
+    return kind_after<WIDE>(r);
 }
 // Runs the walk of every lane of the wave to its end.  `kind`: PT_K_INNER for a lane with a ray, PT_K_DONE for one without.
 template <bool COUNT, class STK, bool TOP = false>
@@ -301,6 +353,30 @@ __device__ __forceinline__ void traverse_scheduled(const SceneView& sc, Ray& r, 
             do { if (kind == PT_K_LEAF) kind = op_leaf<COUNT, STK>(sc, r, stk); count(); } while (cl != 0 && ci < cl && cl >= cs);
         } else {
             if (kind == PT_K_SWITCH) kind = op_switch<COUNT, STK>(sc, r);
+            count();
+        }
+    }
+}
+
+// The same for the tolerance mode: four bodies (binary TLAS node, 4-wide BLAS node, triangle, object switch).
+template <bool COUNT, class STK>
+__device__ __forceinline__ void traverse_scheduled_wide(const SceneView& sc, Ray& r, const STK& stk, int kind) {
+    int ci, cw, cl, cs;
+    auto count = [&]() {
+        ci = __popcll(__ballot(kind == PT_K_INNER)) * sc.sched_wi; cw = __popcll(__ballot(kind == PT_K_WIDE)) * sc.sched_ww;
+        cl = __popcll(__ballot(kind == PT_K_LEAF)) * sc.sched_wl; cs = __popcll(__ballot(kind == PT_K_SWITCH)) * sc.sched_ws;
+    };
+    count();
+    while ((ci | cw | cl | cs) != 0) {
+        if (cw >= ci && cw >= cl && cw >= cs) {
+            do { if (kind == PT_K_WIDE) kind = op_wide<COUNT, STK>(sc, r, stk); count(); } while (cw != 0 && cw >= ci && cw >= cl && cw >= cs);
+        } else if (cl >= ci && cl >= cs) {
+            do { if (kind == PT_K_LEAF) kind = op_leaf<COUNT, STK, true>(sc, r, stk); count(); } while (cl != 0 && cw < cl && cl >= ci && cl >= cs);
+        } else if (ci >= cs) {
+            if (kind == PT_K_INNER) kind = op_inner<COUNT, STK, false, true>(sc, r, stk);
+            count();
+        } else {
+            if (kind == PT_K_SWITCH) kind = op_switch<COUNT, STK, true>(sc, r);
             count();
         }
     }
@@ -348,7 +424,16 @@ __device__ __forceinline__ void publish(unsigned long long ov, unsigned long lon
 // every link of the trip's dependent chain.
 // TOP (with SCHED; SCENE_QUADS is then the LDS budget, not a whole-scene limit): the TLAS, the objects and the tree-top blocks of the
 // meshes (SceneView::top_*) are staged instead of the whole scene, and the walk starts from objects_top (set by the launcher).
-template <int LDS_N, int BLOCK, bool COUNT, int ORDER, bool LOG, bool LOGIC, bool WIDE = false, int SCENE_QUADS = 0, bool SHALLOW = false, bool SCHED = false, bool TOP = false>
+// WIDE (tolerance mode): the walk inside an object uses the 4-wide collapse.  CHECK (with WIDE): the rays of one queue block in
+// rc.check_period -- which ones rotates with the step -- are walked a second time with the reference walk, and how the two walks differ
+// is added up in the StepHeader (chk_*); the wide walk's hit is what the slot gets either way.  The second walk is not done by the wave
+// that did the first: a wave that walks twice lasts twice as long, and a launch of one pool is only one and a half generations of
+// waves deep, so such waves end the launch with a tail of their own wherever they are dispatched (measured: -10 % of the render for
+// 1.6 % of the rays, -24 % when spread over the launch).  Instead the first walk leaves the ray and its hit in a side buffer
+// (rc.chk_buf, two halves by step parity), and the NEXT step's launch starts with rc.chk_cap extra workgroups that take those rays,
+// walk them exactly and compare: they are dispatched first, last as long as an ordinary wave, and share nothing with the other
+// workgroups but the counters.  (pt_render_run always issues at least one step after the last one that traced a ray.)
+template <int LDS_N, int BLOCK, bool COUNT, int ORDER, bool LOG, bool LOGIC, bool WIDE = false, int SCENE_QUADS = 0, bool SHALLOW = false, bool SCHED = false, bool TOP = false, bool CHECK = false>
 __global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView sc, StepHeader* hdr, const int32_t* __restrict__ cam_q,
                                                         const int32_t* __restrict__ mat_q, int32_t* spill, int64_t spill_stride,
                                                         unsigned long long* wave_log, float* __restrict__ image, uint8_t* __restrict__ code_out,
@@ -359,8 +444,45 @@ __global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView 
     // ORDER 2: a launch lasts as long as its longest wave plus the time that wave waited to start
     // (profiles/r01_wave_timeline_*), so the class of rays that held the longest wave in the previous step is dispatched
     // first: queue order when that was a camera wave, reversed when it was a bounce wave (workgroup 0 of the compaction launch decides).
+    typedef Stack<LDS_N, BLOCK, SHALLOW> STK;
+    if (CHECK && (int)blockIdx.x < rc.chk_cap) {
+        // ---- one of the workgroups in front of the launch: the reference walk of the rays the previous step set aside ----
+        const int P = rc.check_period, s = hdr->step_index;      // the compaction launch has already counted this step: s >= 1
+        if (P <= 0) return;
+        const int n_prev = hdr->prev_n_rays, nblk_prev = (n_prev + BLOCK - 1) / BLOCK, pp = (s - 1) % P, x = (int)blockIdx.x;
+        if (pp >= nblk_prev || x >= (nblk_prev - pp + P - 1) / P) return;
+        const bool valid = (x * P + pp) * BLOCK + (int)threadIdx.x < n_prev;
+        const float* S = rc.chk_buf + ((int64_t)(((s - 1) & 1) * rc.chk_cap + x) * 9) * BLOCK + threadIdx.x;
+        Ray e; ray_init(e, F3(0, 0, 1), F3(0, 0, 1), sc.tlas_root);
+        if (valid) ray_init(e, F3(S[0], S[BLOCK], S[2 * BLOCK]), F3(S[3 * BLOCK], S[4 * BLOCK], S[5 * BLOCK]), sc.tlas_root);
+        STK stk{s_stack + threadIdx.x, rc.chk_spill + x * BLOCK + (int)threadIdx.x, (int64_t)rc.chk_cap * BLOCK};
+        traverse_scheduled<false, STK, false>(sc, e, stk, valid ? PT_K_INNER : PT_K_DONE);
+        bool differ = false, flip = false, beyond = false, lost = false; float rel = 0.0f;
+        if (valid) {
+            trav_finish<false>(sc, e);
+            const int w_obj = __float_as_int(S[6 * BLOCK]), w_tri = __float_as_int(S[7 * BLOCK]); const float w_dist = S[8 * BLOCK];
+            differ = w_obj != e.hit_obj || w_tri != e.hit_tri;
+            flip = (w_obj < 0) != (e.hit_obj < 0);
+            if (w_obj >= 0 && e.hit_obj >= 0) rel = __builtin_fabsf(w_dist - e.hit_dist) / e.hit_dist;
+            beyond = flip || rel > 1e-6f;                        // north_star's allowance: "grazing/edge rays within 1e-6"
+            lost = beyond && (w_obj < 0 || (e.hit_obj >= 0 && w_dist > e.hit_dist));
+        }
+        const unsigned long long m_all = __ballot(valid), m_diff = __ballot(differ), m_flip = __ballot(flip), m_bey = __ballot(beyond), m_lost = __ballot(lost);
+        for (int off = 32; off > 0; off >>= 1) rel = fmax_(rel, __shfl_xor(rel, off));
+        if (lane_id() == 0) {
+            atomicAdd(&hdr->chk_rays, (unsigned long long)__popcll(m_all));
+            if (m_diff) atomicAdd(&hdr->chk_mismatch, (unsigned long long)__popcll(m_diff));
+            if (m_flip) atomicAdd(&hdr->chk_flips, (unsigned long long)__popcll(m_flip));
+            if (m_bey) atomicAdd(&hdr->chk_beyond, (unsigned long long)__popcll(m_bey));
+            if (m_lost) atomicAdd(&hdr->chk_lost, (unsigned long long)__popcll(m_lost));
+            if (__float_as_uint(rel) > hdr->chk_max_rel_bits) atomicMax(&hdr->chk_max_rel_bits, __float_as_uint(rel));
+        }
+        publish<false>(e.overflow, 0, 0, 0, 0, hdr);
+        return;
+    }
+    const int bx = (int)blockIdx.x - (CHECK ? rc.chk_cap : 0);
     int nblk = (n_rays + BLOCK - 1) / BLOCK;
-    int blk = (ORDER == 2 && hdr->extend_order) ? nblk - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    int blk = (ORDER == 2 && hdr->extend_order) ? nblk - 1 - bx : bx;
     if (blk < 0 || blk >= nblk) return;
     if (LOG && lane_id() == 0) wave_log[4 * (int64_t)(blockIdx.x * (BLOCK >> 6) + (threadIdx.x >> 6)) + 1] = 0;
     // dynamic LDS, sized by the launcher to the scene's own quads (not to the SCENE_QUADS limit): what a workgroup does not
@@ -383,7 +505,6 @@ __global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView 
     int q = blk * BLOCK + threadIdx.x;
     Ray r; ray_init(r, F3(0, 0, 1), F3(0, 0, 1), sc.tlas_root);
     unsigned code = 0u; int grp = -1;
-    typedef Stack<LDS_N, BLOCK, SHALLOW> STK;
     STK stk{s_stack + threadIdx.x, spill + q, spill_stride};
     int path = -1;
     if (q < n_rays) {
@@ -394,10 +515,20 @@ __global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView 
         ray_init(r, ro, rd, sc.tlas_root);
         if (!SCHED) while (trav_step<COUNT, STK, WIDE>(sc, r, stk)) {}
     }
-    if (SCHED) traverse_scheduled<COUNT, STK, TOP>(sc, r, stk, q < n_rays ? PT_K_INNER : PT_K_DONE, (LdsQuads)s_scene);     // the whole wave walks together
+    if (SCHED && WIDE) traverse_scheduled_wide<COUNT, STK>(sc, r, stk, q < n_rays ? PT_K_INNER : PT_K_DONE);
+    else if (SCHED) traverse_scheduled<COUNT, STK, TOP>(sc, r, stk, q < n_rays ? PT_K_INNER : PT_K_DONE, (LdsQuads)s_scene);     // the whole wave walks together
     if (q < n_rays) {
         trav_finish<COUNT>(sc, r);
         ps.hit[path] = make_int2(r.hit_obj, r.hit_tri);
+    }
+    if (CHECK && rc.check_period > 0 && blk % rc.check_period == hdr->step_index % rc.check_period && q < n_rays) {
+        // set aside for the reference walk at the front of the next step's launch (generate_one has stored the camera ray)
+        float* S = rc.chk_buf + ((int64_t)((hdr->step_index & 1) * rc.chk_cap + blk / rc.check_period) * 9) * BLOCK + threadIdx.x;
+        const P3 so = ps.path_o[path], sd = ps.path_d[path];
+        S[0] = so.x; S[BLOCK] = so.y; S[2 * BLOCK] = so.z; S[3 * BLOCK] = sd.x; S[4 * BLOCK] = sd.y; S[5 * BLOCK] = sd.z;
+        S[6 * BLOCK] = __int_as_float(r.hit_obj); S[7 * BLOCK] = __int_as_float(r.hit_tri); S[8 * BLOCK] = r.hit_dist;
+    }
+    if (q < n_rays) {
         if (LOGIC) {
             code = logic_one(ps, image, path, r.hit_obj >= 0, rc.max_nb);
             code_out[path] = (uint8_t)code;
@@ -471,7 +602,7 @@ static int64_t pad_to(int64_t n, int64_t m) { return (n + m - 1) / m * m; }
 // The spill is sized for the smallest LDS share any variant uses (12 entries) and the largest slot count.
 size_t ptk_spill_ints(int64_t n_rays) { return (size_t)pad_to(n_rays, 256) * (PT_STACK_SIZE - PT_STAGED_LDS_STACK); }
 
-template <int LDS_N, int BLOCK, int ORDER, bool WIDE = false, int SCENE_QUADS = 0, bool SHALLOW = false, bool SCHED = false, bool TOP = false>
+template <int LDS_N, int BLOCK, int ORDER, bool WIDE = false, int SCENE_QUADS = 0, bool SHALLOW = false, bool SCHED = false, bool TOP = false, bool CHECK = false>
 static void launch_queue(const PathState& ps, int num_paths, int grid_rays, SceneView sc, StepHeader* hdr, const int32_t* cam_q,
                          const int32_t* mat_q, int32_t* spill, int count, unsigned long long* wave_log, float* image, uint8_t* code,
                          unsigned long long* rec_next, const RenderConst& rc, hipStream_t s) {
@@ -481,7 +612,8 @@ static void launch_queue(const PathState& ps, int num_paths, int grid_rays, Scen
     dim3 grid((unsigned)((std::max(1, std::min(num_paths, grid_rays)) + BLOCK - 1) / BLOCK));
     const size_t scene_lds = TOP ? 16 * (size_t)(12 * sc.n_objects + 4 * sc.top_nodes) : SCENE_QUADS > 0 ? 16 * (size_t)(12 * sc.n_objects + 7 * sc.n_tris) : 0;
     if (TOP) sc.objects = sc.objects_top;
-#define PT_LAUNCH(COUNT, LOG, LOGIC) hipLaunchKernelGGL((k_extend_queue<LDS_N, BLOCK, COUNT, ORDER, LOG, LOGIC, WIDE, SCENE_QUADS, SHALLOW, SCHED, TOP>), grid, dim3(BLOCK), scene_lds, s, ps, sc, hdr, \
+#define PT_LAUNCH(COUNT, LOG, LOGIC) hipLaunchKernelGGL((k_extend_queue<LDS_N, BLOCK, COUNT, ORDER, LOG, LOGIC, WIDE, SCENE_QUADS, SHALLOW, SCHED, TOP, CHECK && LOGIC && !(COUNT)>), \
+                                                       dim3(grid.x + ((CHECK && LOGIC && !(COUNT)) ? (unsigned)rc.chk_cap : 0u)), dim3(BLOCK), scene_lds, s, ps, sc, hdr, \
                                                        cam_q, mat_q, spill, stride, wave_log, image, code, rec_next, rc)
     if (wave_log)    PT_LAUNCH(false, true, false);    // measurement replays (code == null): traversal only, idempotent
     else if (!code)  PT_LAUNCH(false, false, false);
@@ -514,7 +646,11 @@ const char* ptk_extend_variant_name(int v) { return (v >= 0 && v < 7) ? kVariant
 void ptk_extend_queue(const PathState& ps, const RenderConst& rc, const SceneView& sc, StepHeader* hdr, const int32_t* cam_q,
                       const int32_t* mat_q, int32_t* spill, int count, int variant, unsigned long long* wave_log, float* image, uint8_t* code,
                       unsigned long long* rec_next, int grid_rays, hipStream_t s) {
-    if (sc.wide)           launch_queue<16, 64, 2, true>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);   // fast mode
+    if (sc.wide && variant == 2)                                                                                                                                         // tolerance mode, per-lane loop (A/B)
+        launch_queue<16, 64, 2, true>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
+    else if (sc.wide && rc.check_period > 0)                                                                                                                             // tolerance mode, kind-scheduled, sampled exact re-walk
+        launch_queue<16, 64, 2, true, 0, false, true, false, true>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
+    else if (sc.wide)      launch_queue<16, 64, 2, true, 0, false, true>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
     else if (variant == 0) launch_queue<24, 256, 1>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
     else if (variant == 1) launch_queue<16, 64, 1>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
     else if (variant >= 3 && 12 * (int64_t)sc.n_objects + 7 * (int64_t)sc.n_tris <= PT_SCENE_LDS_QUADS) {

@@ -112,6 +112,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_compact_generate_shade(PathState p
         unsigned cam = __shfl((int)v, 0), mat = __shfl((int)v, 1);
         if (lane == 0) {
             hdr->extend_order = mat > cam ? 1 : 0;
+            hdr->prev_n_rays = hdr->n_rays;
             hdr->n_camera = t.x; hdr->n_material = t.y; hdr->n_rays = t.x + t.y;
             hdr->ticket_base = ticket_base;
             hdr->pixel_counter = ticket_base + t.z;

@@ -430,8 +430,10 @@ class PooledPathTracer:
         capi.check(lib, self.device.ctx, lib.pt_render_run_many(ctxs, n, int(max_steps), flags, rs), "pt_render_run_many")
         out = capi.PtRunStats()
         out.steps = max(r.steps for r in rs)
-        for f in ("total_rays", "total_samples", "stack_overflows", "extend_launches", "traversal_bytes", "wasted_rays"):
+        for f in ("total_rays", "total_samples", "stack_overflows", "extend_launches", "traversal_bytes", "wasted_rays",
+                  "checked_rays", "mismatched_rays", "flipped_rays", "beyond_tolerance_rays", "lost_hit_rays"):
             setattr(out, f, sum(getattr(r, f) for r in rs))
+        out.max_rel_dist_diff = max(r.max_rel_dist_diff for r in rs)
         out.extend_ms = sum(r.extend_ms for r in rs)
         self.last_pool_stats = list(rs)
         return out

@@ -30,7 +30,7 @@ def test_struct_sizes_match_header(pta):
     c = pta.capi
     assert ctypes.sizeof(c.PtInstance) == 160
     assert ctypes.sizeof(c.PtRenderParams) == 4 * 2 + 12 + 12 + 4 + 4 + 4 + 4 + 8 * 3 + 8   # with natural padding
-    assert ctypes.sizeof(c.PtRunStats) == 64 and ctypes.sizeof(c.PtStepStats) == 32
+    assert ctypes.sizeof(c.PtRunStats) == 112 and ctypes.sizeof(c.PtStepStats) == 32
 
 
 def test_no_gpu_is_a_loud_error(pta):
