@@ -99,6 +99,7 @@ SIGNATURES = {
     "pt_get_traversal_mode": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "pt_set_traversal_check": (C.c_int, [C.c_void_p, C.c_int]),
     "pt_extend_replay": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "pt_extend_pass_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "pt_extend_wave_log": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "pt_tonemap_rgba8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
 }

@@ -332,7 +332,8 @@ __device__ __forceinline__ int op_switch(const SceneView& sc, Ray& r) {
 }
 // Runs the walk of every lane of the wave to its end.  `kind`: PT_K_INNER for a lane with a ray, PT_K_DONE for one without.
 template <bool COUNT, class STK, bool TOP = false>
-__device__ __forceinline__ void traverse_scheduled(const SceneView& sc, Ray& r, const STK& stk, int kind, LdsQuads lds = nullptr) {
+__device__ __forceinline__ void traverse_scheduled(const SceneView& sc, Ray& r, const STK& stk, int kind, LdsQuads lds = nullptr, StepHeader* hdr = nullptr) {
+    int np_i = 0, np_l = 0, np_s = 0;      // COUNT: passes by body (measurement: lane use = lane visits / (64 x passes))
     // Same sequence of passes as "count, choose, run one body" in one loop; written as a tight loop per body inside the outer loop so
     // that a run of passes of one kind keeps the values that body does not touch where they are (no copies at the joins).
     int ci, cl, cs;
@@ -348,20 +349,23 @@ __device__ __forceinline__ void traverse_scheduled(const SceneView& sc, Ray& r, 
     count();
     while ((ci | cl | cs) != 0) {
         if (ci >= cl && ci >= cs) {
-            do { if (kind == PT_K_INNER) kind = op_inner<COUNT, STK, TOP>(sc, r, stk, lds); count(); } while (ci != 0 && ci >= cl && ci >= cs);
+            do { if (kind == PT_K_INNER) kind = op_inner<COUNT, STK, TOP>(sc, r, stk, lds); count(); if (COUNT) np_i++; } while (ci != 0 && ci >= cl && ci >= cs);
         } else if (cl >= cs) {
-            do { if (kind == PT_K_LEAF) kind = op_leaf<COUNT, STK>(sc, r, stk); count(); } while (cl != 0 && ci < cl && cl >= cs);
+            do { if (kind == PT_K_LEAF) kind = op_leaf<COUNT, STK>(sc, r, stk); count(); if (COUNT) np_l++; } while (cl != 0 && ci < cl && cl >= cs);
         } else {
             if (kind == PT_K_SWITCH) kind = op_switch<COUNT, STK>(sc, r);
-            count();
+            count(); if (COUNT) np_s++;
         }
+    }
+    if (COUNT && hdr && lane_id() == 0) {
+        atomicAdd(&hdr->passes[0], (unsigned long long)np_i); atomicAdd(&hdr->passes[2], (unsigned long long)np_l); atomicAdd(&hdr->passes[3], (unsigned long long)np_s);
     }
 }
 
 // The same for the tolerance mode: four bodies (binary TLAS node, 4-wide BLAS node, triangle, object switch).
 template <bool COUNT, class STK>
-__device__ __forceinline__ void traverse_scheduled_wide(const SceneView& sc, Ray& r, const STK& stk, int kind) {
-    int ci, cw, cl, cs;
+__device__ __forceinline__ void traverse_scheduled_wide(const SceneView& sc, Ray& r, const STK& stk, int kind, StepHeader* hdr = nullptr) {
+    int ci, cw, cl, cs, np_i = 0, np_w = 0, np_l = 0, np_s = 0;
     auto count = [&]() {
         ci = __popcll(__ballot(kind == PT_K_INNER)) * sc.sched_wi; cw = __popcll(__ballot(kind == PT_K_WIDE)) * sc.sched_ww;
         cl = __popcll(__ballot(kind == PT_K_LEAF)) * sc.sched_wl; cs = __popcll(__ballot(kind == PT_K_SWITCH)) * sc.sched_ws;
@@ -369,16 +373,20 @@ __device__ __forceinline__ void traverse_scheduled_wide(const SceneView& sc, Ray
     count();
     while ((ci | cw | cl | cs) != 0) {
         if (cw >= ci && cw >= cl && cw >= cs) {
-            do { if (kind == PT_K_WIDE) kind = op_wide<COUNT, STK>(sc, r, stk); count(); } while (cw != 0 && cw >= ci && cw >= cl && cw >= cs);
+            do { if (kind == PT_K_WIDE) kind = op_wide<COUNT, STK>(sc, r, stk); count(); if (COUNT) np_w++; } while (cw != 0 && cw >= ci && cw >= cl && cw >= cs);
         } else if (cl >= ci && cl >= cs) {
-            do { if (kind == PT_K_LEAF) kind = op_leaf<COUNT, STK, true>(sc, r, stk); count(); } while (cl != 0 && cw < cl && cl >= ci && cl >= cs);
+            do { if (kind == PT_K_LEAF) kind = op_leaf<COUNT, STK, true>(sc, r, stk); count(); if (COUNT) np_l++; } while (cl != 0 && cw < cl && cl >= ci && cl >= cs);
         } else if (ci >= cs) {
             if (kind == PT_K_INNER) kind = op_inner<COUNT, STK, false, true>(sc, r, stk);
-            count();
+            count(); if (COUNT) np_i++;
         } else {
             if (kind == PT_K_SWITCH) kind = op_switch<COUNT, STK, true>(sc, r);
-            count();
+            count(); if (COUNT) np_s++;
         }
+    }
+    if (COUNT && hdr && lane_id() == 0) {
+        atomicAdd(&hdr->passes[0], (unsigned long long)np_i); atomicAdd(&hdr->passes[1], (unsigned long long)np_w);
+        atomicAdd(&hdr->passes[2], (unsigned long long)np_l); atomicAdd(&hdr->passes[3], (unsigned long long)np_s);
     }
 }
 
@@ -515,8 +523,8 @@ __global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView 
         ray_init(r, ro, rd, sc.tlas_root);
         if (!SCHED) while (trav_step<COUNT, STK, WIDE>(sc, r, stk)) {}
     }
-    if (SCHED && WIDE) traverse_scheduled_wide<COUNT, STK>(sc, r, stk, q < n_rays ? PT_K_INNER : PT_K_DONE);
-    else if (SCHED) traverse_scheduled<COUNT, STK, TOP>(sc, r, stk, q < n_rays ? PT_K_INNER : PT_K_DONE, (LdsQuads)s_scene);     // the whole wave walks together
+    if (SCHED && WIDE) traverse_scheduled_wide<COUNT, STK>(sc, r, stk, q < n_rays ? PT_K_INNER : PT_K_DONE, hdr);
+    else if (SCHED) traverse_scheduled<COUNT, STK, TOP>(sc, r, stk, q < n_rays ? PT_K_INNER : PT_K_DONE, (LdsQuads)s_scene, hdr);     // the whole wave walks together
     if (q < n_rays) {
         trav_finish<COUNT>(sc, r);
         ps.hit[path] = make_int2(r.hit_obj, r.hit_tri);
