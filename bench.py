@@ -41,6 +41,9 @@ CONFIGS = {
     # the scene description carries them in desc["settings"])
     "instanced_ext": ("instanced_scene_ext", {}, 3840, 2160, 32, 4),
 }
+# The 4K configs are also rendered with the tolerance-mode traversal north_star allows ("hit indices bit-exact, except for counted
+# grazing/edge rays within 1e-6"): both modes in one line, the differing rays counted, the frames compared at equal spp.
+BOTH_MODES = {"grid", "instanced", "instanced_ext"}
 
 
 def build_scene(pta, dev, name):
@@ -78,10 +81,11 @@ def main():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--spp", type=int, default=0)
-    ap.add_argument("--paths", type=int, default=750_000,
-                    help="path slots per pool (the reference has one pool of 1,000,000, path-tracer.js:4); 3 pools of 750,000 is the measured optimum "
-                         "on MI355X, one pool of 2,000,000 the best single pool (profiles/r01_pool_size_sweep_v3.json)")
-    ap.add_argument("--pools", type=int, default=3,
+    ap.add_argument("--paths", type=int, default=0,
+                    help="path slots per pool (the reference has one pool of 1,000,000, path-tracer.js:4).  0 = host.default_pool_shape: 3 pools of a "
+                         "quarter of the frame's pixels each, between 750,000 (1080p) and 2,000,000 (4K) -- the measured optima "
+                         "(profiles/r01_pool_size_sweep_v3.json, profiles/r03_pool_shape_and_weight_sweeps.txt)")
+    ap.add_argument("--pools", type=int, default=0,
                     help="independent path pools per GPU, --paths slots each, driven together on their own streams (pt_render_run_many)")
     ap.add_argument("--roofline-paths", type=int, default=2_000_000, help="slots of the single pool of the exclusive roofline pass")
     ap.add_argument("--no-extras", action="store_true", help="skip the exclusive roofline pass, the reference-shaped pool and the configs[1] render")
@@ -115,6 +119,8 @@ def main():
     pta = importlib.import_module("path-tracer_amd")
     _, _, w, h, spp, cfg_index = CONFIGS[args.config]
     w, h, spp = args.width or w, args.height or h, args.spp or spp
+    d_pools, d_paths = pta.host.default_pool_shape(w, h)
+    args.pools, args.paths = args.pools or d_pools, args.paths or d_paths
 
     stream = torch.cuda.current_stream().cuda_stream
     dev = pta.request_device(gpu, stream=stream)
@@ -197,6 +203,9 @@ def main():
         if args.fast:
             out["tolerance_check"] = {"rays_rewalked_exactly": checked, "different_hit": mismatched, "hit_vs_miss": flipped, "beyond_1e-6": beyond, "of_those_reference_hit_lost": lost, "max_rel_hit_dist_diff": max_rel,
                                       "share_rewalked": round(checked / max(rays, 1), 5)}
+        if world == 1 and args.config in BOTH_MODES and not args.no_extras:
+            out["other_mode"] = other_mode_pass(pta, gpu, args, w, h, spp, img, args.fast)
+            out["tolerance_mode_full_check"] = full_check_pass(pta, gpu, args, w, h, spp)
         if not args.no_extras:
             out["roofline"] = roofline_pass(pta, dev, scene, desc, args, w, h, spp)
             out["reference_pool_shape"] = reference_shape_pass(pta, dev, scene, desc, w, h, spp)
@@ -304,15 +313,76 @@ def other_config_pass(pta, gpu, name, args):
     try:
         desc, scene, _ = build_scene(pta, dev, name)
         info = scene.info()
+        pools, paths = pta.host.default_pool_shape(w, h)
         pt = pta.init_path_tracer({"device": dev, "scene": scene, "image": {"width": w, "height": h}, "camera": desc["camera"],
-                                   "settings": {"samples": spp, "numPaths": args.paths, "pools": args.pools}})
+                                   "settings": {"samples": spp, "numPaths": paths, "pools": pools}})
         pt.run()
         sec, rs, rays, _, _ = timed_renders(pt, 3)
         pt.destroy()
     finally:
         dev.destroy()
-    return {"workload": f"BASELINE configs[{idx}] {name}: {info.n_tris} tris / {info.n_objects} instances, {w}x{h}, {spp} spp, {args.pools} pool(s) of {args.paths} path slots",
+    return {"workload": f"BASELINE configs[{idx}] {name}: {info.n_tris} tris / {info.n_objects} instances, {w}x{h}, {spp} spp, {pools} pool(s) of {paths} path slots",
             "Mrays_per_s": round(rays / sec / 1e6, 3), "ms_per_render": round(sec / 3 * 1e3, 3), "renders": 3}
+
+
+def other_mode_pass(pta, gpu, args, w, h, spp, main_image, main_is_tolerance):
+    """The same frame in the OTHER traversal mode (reference-exact <-> tolerance mode), on a context of its own with the same pools:
+    1 warm-up + args.steps timed renders, then the two finished frames compared at equal spp.  The tolerance-mode render of the pair also
+    runs once more with EVERY ray re-walked exactly (check period 1) for the full count of differing rays."""
+    dev = pta.request_device(gpu)
+    tol = not main_is_tolerance
+    try:
+        if tol:
+            dev.call("pt_set_traversal_mode", pta.capi.PT_TRAVERSAL_WIDE)
+            if args.check_period >= 0:
+                dev.call("pt_set_traversal_check", args.check_period)
+        desc, scene, _ = build_scene(pta, dev, args.config)
+        settings = dict({"samples": spp, "numPaths": args.paths, "pools": args.pools}, **desc.get("settings", {}))
+        pt = pta.init_path_tracer({"device": dev, "scene": scene, "image": {"width": w, "height": h}, "camera": desc["camera"], "settings": settings})
+        pt.run()
+        sec, rs, rays, _, _ = timed_renders(pt, args.steps)
+        img = pt.read_image().astype(np.float64)
+        res = {"mode": "tolerance (4-wide collapse, pt_set_traversal_mode PT_TRAVERSAL_WIDE)" if tol else "reference-exact",
+               "Mrays_per_s": round(rays / sec / 1e6, 3), "ms_per_render": round(sec / args.steps * 1e3, 3), "renders": args.steps,
+               "rays_per_render": int(rs.total_rays)}
+        if tol:
+            res["sampled_check_in_the_timed_renders"] = check_block(rs)
+        pt.destroy()
+    finally:
+        dev.destroy()
+    ref = main_image.astype(np.float64)
+    a, b = img[..., :3] / np.maximum(img[..., 3:], 1.0), ref[..., :3] / np.maximum(ref[..., 3:], 1.0)
+    rmse, mean = float(np.sqrt(((a - b) ** 2).mean())), float(b.mean())
+    differing = int((np.abs(a - b).max(axis=-1) > 1e-5 * np.maximum(np.abs(b).max(axis=-1), 1e-3)).sum())
+    res["frame_vs_the_other_mode_at_equal_spp"] = {"rmse": rmse, "rmse_over_mean_radiance": rmse / mean, "pixels_differing_by_more_than_1e-5_relative": differing,
+                                                  "pixels": int(w * h), "sample_counts_equal": bool(np.array_equal(img[..., 3], ref[..., 3])),
+                                                  "note": "a ray with another hit index forks its path; from then on its slot finishes at other steps, pixel tickets go to other slots "
+                                                          "(other random streams), and the rest of the frame is another sample of the same estimator: the two frames agree like two "
+                                                          "renders with different seeds.  At 8 spp (one ticket per pixel) only the forked pixels differ: tests/test_gpu_full_size.py"}
+    return res
+
+
+def full_check_pass(pta, gpu, args, w, h, spp):
+    """One tolerance-mode render of the frame in which EVERY ray is walked a second time exactly (check period 1): the full count of
+    rays whose closest hit differs from the reference walk's, and the largest relative hit-distance difference."""
+    dev = pta.request_device(gpu)
+    try:
+        dev.call("pt_set_traversal_mode", pta.capi.PT_TRAVERSAL_WIDE)
+        dev.call("pt_set_traversal_check", 1)
+        desc, scene, _ = build_scene(pta, dev, args.config)
+        settings = dict({"samples": spp, "numPaths": args.paths, "pools": args.pools}, **desc.get("settings", {}))
+        pt = pta.init_path_tracer({"device": dev, "scene": scene, "image": {"width": w, "height": h}, "camera": desc["camera"], "settings": settings})
+        rs = pt.run()
+        pt.destroy()
+    finally:
+        dev.destroy()
+    return check_block(rs)
+
+
+def check_block(rs):
+    return {"rays": int(rs.total_rays), "rays_rewalked_exactly": int(rs.checked_rays), "different_hit": int(rs.mismatched_rays), "hit_vs_miss": int(rs.flipped_rays),
+            "hit_dist_apart_by_more_than_1e-6": int(rs.beyond_tolerance_rays), "of_those_a_reference_hit_was_lost": int(rs.lost_hit_rays),
+            "max_rel_hit_dist_diff": float(rs.max_rel_dist_diff)}
 
 
 def cpu_baseline(pta, desc, w, h, spp, paths):

@@ -452,6 +452,14 @@ class PooledPathTracer:
             pt.device.destroy()
 
 
+def default_pool_shape(width, height):
+    """(pools, numPaths) the hosts use when the caller fixes neither: three pools of a quarter of the frame's pixels each, between 750,000
+    slots (the optimum at 1080p) and 2,000,000 (the optimum at 4K); profiles/r01_pool_size_sweep_v3.json,
+    profiles/r03_pool_shape_and_weight_sweeps.txt.  The reference has one pool of 1,000,000 (path-tracer.js:4); the shape only changes
+    which random stream renders which pixel ticket and when launches run (each pool is bit-identical to the oracle's run of its share)."""
+    return 3, int(min(2_000_000, max(750_000, width * height // 4)))
+
+
 def init_path_tracer(params):
     if int(params["settings"].get("pools", 1)) > 1:
         return PooledPathTracer(params)

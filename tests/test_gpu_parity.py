@@ -409,9 +409,10 @@ def test_debug_view(pta, orc, device, built):
 ONE_TRI = "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3"
 
 
-def test_fast_mode_closest_hits(pta, device, built):
-    """SURVEY 8f.4 fast mode (compressed 4-wide BVH; outside the bit-exact contract): the closest hit is the reference-exact
-    mode's except for ties between equidistant triangles; hit distances agree to 1e-6 relative."""
+def test_tolerance_mode_closest_hits(pta, device, built):
+    """SURVEY 8f.4 / north_star's allowance ("hit indices bit-exact, except for counted grazing/edge rays within 1e-6"): with the
+    compressed 4-wide BVH the closest hit is the reference-exact mode's except for ties between equidistant triangles; hit distances
+    agree to 1e-6 relative.  (pt_trace_rays: one lane per ray, boxes decoded outwards, so no hit the reference finds can be lost.)"""
     one_tri = {"meshes": [{"file": ONE_TRI}, {"file": pta.scenes.FLOOR_OBJ}],
                "instances": [(0, [0, 0, 1], [0.3, 0.2, 0.1], [2, 2, 2], 0), (0, [1, 1, 2], [0, 0, 0], [1, 1, 1], 1), (1, [0, 0, 0], [0, 0, 0], [1, 1, 1], 0)],
                "camera": {"position": [0.5, 0.5, 6], "lookAt": [0.5, 0.6, 0], "fov": 30}}
@@ -444,9 +445,12 @@ def test_fast_mode_closest_hits(pta, device, built):
         dev2.destroy()
 
 
-def test_fast_mode_render(pta, orc, device, built):
-    """A fast-mode render: every pixel gets exactly spp samples, the frame agrees with the reference-exact frame statistically
-    (paths fork where a hit distance differs in its last bits), and switching back restores bit-exact oracle parity."""
+def test_tolerance_mode_render_counts_its_differing_rays(pta, orc, device, built):
+    """A tolerance-mode render: every pixel gets exactly spp samples; with the check period at 1 EVERY traced ray is walked a second
+    time exactly (by the workgroups in front of the next step's launch) and the differences are counted: none beyond 1e-6, no reference
+    hit lost; the frame agrees with the reference-exact frame (paths only fork at a ray whose hit index differs); switching back restores
+    bit-exact oracle parity.  PT_TRAVERSAL_AUTO keeps the reference walk for a scene this small."""
+    import ctypes as C
     desc, s, o = built("cornell")
     w, h, spp, paths = 96, 54, 64, 20000
     def render():
@@ -454,12 +458,29 @@ def test_fast_mode_render(pta, orc, device, built):
                                    "settings": {"samples": spp, "numPaths": paths}})
         rs = pt.run()
         return pt, rs, pt.read_image()
+    mode = C.c_int(-1)
     try:
+        device.call("pt_set_traversal_mode", pta.capi.PT_TRAVERSAL_AUTO)
+        device.call("pt_get_traversal_mode", C.byref(mode))
+        assert mode.value == pta.capi.PT_TRAVERSAL_REFERENCE
         device.call("pt_set_traversal_mode", pta.capi.PT_TRAVERSAL_WIDE)
+        device.call("pt_get_traversal_mode", C.byref(mode))
+        assert mode.value == pta.capi.PT_TRAVERSAL_WIDE
+        device.call("pt_set_traversal_check", 1)
         _, rs_f, img_f = render()
+        assert rs_f.checked_rays == rs_f.total_rays > 0
+        assert rs_f.mismatched_rays <= 1e-3 * rs_f.checked_rays and rs_f.beyond_tolerance_rays == 0 and rs_f.lost_hit_rays == 0 and rs_f.flipped_rays == 0
+        assert rs_f.max_rel_dist_diff <= 1e-6
+        device.call("pt_set_traversal_check", 7)
+        _, rs_7, img_7 = render()
+        assert 0 < rs_7.checked_rays < rs_f.total_rays / 5 and rs_7.lost_hit_rays == 0
+        np.testing.assert_array_equal(img_7[..., 3], img_f[..., 3])            # the re-walk never touches a result (float adds into a pixel are unordered)
+        np.testing.assert_allclose(img_7[..., :3], img_f[..., :3], rtol=1e-5, atol=1e-6)
     finally:
+        device.call("pt_set_traversal_check", 256)
         device.call("pt_set_traversal_mode", pta.capi.PT_TRAVERSAL_REFERENCE)
     pt, rs_e, img_e = render()
+    assert rs_e.checked_rays == 0
     assert rs_f.total_samples == rs_e.total_samples == w * h * spp and rs_f.stack_overflows == 0
     np.testing.assert_array_equal(img_f[..., 3], np.full((h, w), spp, np.float32))
     rad_f, rad_e = img_f[..., :3] / spp, img_e[..., :3] / spp
