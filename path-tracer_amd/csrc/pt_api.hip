@@ -158,7 +158,13 @@ int scene_stack_bound(pt_ctx* c) {
 
 // 8 waves/SIMD, class of the longest wave first, a tiny scene staged in LDS, kind-scheduled walk: +7...13 % over variant 3 on scenes
 // with 2 to 101 objects and, with the inner body's weight at 3 (scene_view), +2.5 % on a one-object scene (profiles/r02_sched_weight_sweep.txt).
-int extend_variant_of(const pt_ctx* c) { return c->extend_variant >= 0 ? c->extend_variant : 4; }
+// The kind-scheduled bodies address records through 32-bit byte offsets (pt_kernels_extend.hip rec32): scenes with 2^26 or more records in
+// one array (4 GB of nodes) take the per-lane loop of variant 2, which addresses with 64 bits.
+bool fits_32bit_offsets(const pt_ctx* c) { return c->n_tris + c->n_objects + c->top_nodes < (1ll << 26) && c->n_wide < (1ll << 26); }
+int extend_variant_of(const pt_ctx* c) {
+    const int v = c->extend_variant >= 0 ? c->extend_variant : 4;
+    return fits_32bit_offsets(c) ? v : std::min(v, 2);
+}
 
 // PT_TRAVERSAL_AUTO: the wide walk pays where the binary nodes do not stay in the caches -- they are 64 B per triangle, and the chip
 // has 8 x 4 MB of L2 in front of a 256 MB memory-side cache (measured, profiles/r03_mode_crossover.txt: 32 MB of nodes, 100 instances of
@@ -339,7 +345,7 @@ int write_header(pt_ctx* c) {
     HIPOK(c, hipStreamSynchronize(c->stream));
     {   // tolerance mode: the re-walk period is fixed for the render that starts here
         RenderConst& rc = c->rc;
-        rc.check_period = wide_in_use(c) ? c->check_period : 0;
+        rc.check_period = (wide_in_use(c) && fits_32bit_offsets(c)) ? c->check_period : 0;   // the re-walk is a kind-scheduled walk
         rc.chk_cap = rc.check_period > 0 ? ((rc.num_paths + 63) / 64 + rc.check_period - 1) / rc.check_period : 0;
         if (rc.chk_cap > c->chk_cap_alloc) {
             dfree(c->d_chk_buf); dfree(c->d_chk_spill); c->d_chk_buf = nullptr; c->d_chk_spill = nullptr; c->chk_cap_alloc = 0;

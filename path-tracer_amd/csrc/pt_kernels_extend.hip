@@ -13,6 +13,12 @@
 #include <algorithm>
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+// record `idx` of an array of QUADS-quad records through a 32-bit byte offset from the (wave-uniform) base: one shift instead of 64-bit
+// address arithmetic (global_load ... v_offset, s[base]).  Only the kind-scheduled bodies use it; the host sends scenes with 2^26 or
+// more records in an array to the per-lane loop, which addresses with 64 bits (pt_api.hip extend_variant_of).
+template <int QUADS> __device__ __forceinline__ const float4* rec32(const float4* base, int idx) {
+    return (const float4*)((const char*)base + (uint32_t)idx * (uint32_t)(16 * QUADS));
+}
 __device__ __forceinline__ int rank_below(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
 }
@@ -23,17 +29,19 @@ template <int LDS_N, int BLOCK, bool SHALLOW = false>
 struct Stack {
     static constexpr bool shallow = SHALLOW;
     int* lds;            // &s_stack[0][thread]
-    int32_t* spill;      // &spill[0][slot]
+    int32_t* spill_base; // &spill[0][0] (wave-uniform: the lane's address is only formed on the rare path that needs it)
+    int slot;            // this lane's slot in a spill entry
     int64_t stride;      // slots per spill entry
+    __device__ __forceinline__ int32_t* spill_at(int sp) const { return spill_base + ((int64_t)(sp - LDS_N) * stride + slot); }
     // Whether any lane of the wave is past the LDS part is ONE wave-uniform branch; the per-lane choice between LDS and
     // spill (exec-mask bookkeeping on the scalar unit, which a CU's 32 waves share) is only made behind it.
     __device__ __forceinline__ void put(int sp, int v) const {
         if (SHALLOW || !__any(sp >= LDS_N)) lds[sp * BLOCK] = v;
-        else if (sp < LDS_N) lds[sp * BLOCK] = v; else spill[(int64_t)(sp - LDS_N) * stride] = v;
+        else if (sp < LDS_N) lds[sp * BLOCK] = v; else *spill_at(sp) = v;
     }
     __device__ __forceinline__ int get(int sp) const {               // sp = -1 ends the loop; the value read then is not used
         if (SHALLOW || !__any(sp >= LDS_N)) return lds[(sp < 0 ? 0 : sp) * BLOCK];
-        return sp < 0 ? 0 : (sp < LDS_N ? lds[sp * BLOCK] : spill[(int64_t)(sp - LDS_N) * stride]);
+        return sp < 0 ? 0 : (sp < LDS_N ? lds[sp * BLOCK] : *spill_at(sp));
     }
     static constexpr int lds_n = LDS_N;
     static constexpr int block = BLOCK;
@@ -228,7 +236,7 @@ __device__ __forceinline__ int op_inner(const SceneView& sc, Ray& r, const STK& 
         const v4f a = nd[0], b = nd[1], c = nd[2], d = nd[3];
         q0 = make_float4(a.x, a.y, a.z, a.w); q1 = make_float4(b.x, b.y, b.z, b.w); q2 = make_float4(c.x, c.y, c.z, c.w); q3 = make_float4(d.x, d.y, d.z, d.w);
     } else {
-        const float4* nd = sc.nodes + 4 * (int64_t)r.node;
+        const float4* nd = rec32<4>(sc.nodes, r.node);
         q0 = nd[0]; q1 = nd[1]; q2 = nd[2]; q3 = nd[3];
     }
     if (COUNT) r.n_inner += stop ? 0 : 1;
@@ -269,7 +277,7 @@ template <bool COUNT, class STK>
 __device__ __forceinline__ int op_wide(const SceneView& sc, Ray& r, const STK& stk) {
     r.iter++;
     const bool stop = !STK::shallow && r.iter > PT_MAX_ITERS;
-    const float4* nd = sc.wide + PT_WIDE_QUADS * (int64_t)r.node;
+    const float4* nd = rec32<PT_WIDE_QUADS>(sc.wide, r.node);
     const float4 h = nd[0], rf = nd[1], qa = nd[2], qb = nd[3];
     if (COUNT) r.n_inner += stop ? 0 : 1;                       // one 64-B record
     const unsigned eb = __float_as_uint(h.w);
@@ -308,7 +316,7 @@ __device__ __forceinline__ int op_leaf(const SceneView& sc, Ray& r, const STK& s
     r.iter++;
     const bool stop = !STK::shallow && r.iter > PT_MAX_ITERS;                // as in op_inner: one exit; a stopped lane's test changes nothing
     int t = -(r.node + 1);
-    const float4* tr = sc.tris + 3 * (int64_t)t;
+    const float4* tr = rec32<3>(sc.tris, t);
     float dist = tri_hit(r.o, r.d, tr[0], tr[1], tr[2]);
     if (!stop && dist > 0.0f && dist < r.hit_dist) { r.hit_dist = dist; r.hit_tri = t; r.hit_obj = r.obj; }
     if (COUNT) r.n_leaf += stop ? 0 : 1;
@@ -463,7 +471,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView 
         const float* S = rc.chk_buf + ((int64_t)(((s - 1) & 1) * rc.chk_cap + x) * 9) * BLOCK + threadIdx.x;
         Ray e; ray_init(e, F3(0, 0, 1), F3(0, 0, 1), sc.tlas_root);
         if (valid) ray_init(e, F3(S[0], S[BLOCK], S[2 * BLOCK]), F3(S[3 * BLOCK], S[4 * BLOCK], S[5 * BLOCK]), sc.tlas_root);
-        STK stk{s_stack + threadIdx.x, rc.chk_spill + x * BLOCK + (int)threadIdx.x, (int64_t)rc.chk_cap * BLOCK};
+        STK stk{s_stack + threadIdx.x, rc.chk_spill, x * BLOCK + (int)threadIdx.x, (int64_t)rc.chk_cap * BLOCK};
         traverse_scheduled<false, STK, false>(sc, e, stk, valid ? PT_K_INNER : PT_K_DONE);
         bool differ = false, flip = false, beyond = false, lost = false; float rel = 0.0f;
         if (valid) {
@@ -513,7 +521,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView 
     int q = blk * BLOCK + threadIdx.x;
     Ray r; ray_init(r, F3(0, 0, 1), F3(0, 0, 1), sc.tlas_root);
     unsigned code = 0u; int grp = -1;
-    STK stk{s_stack + threadIdx.x, spill + q, spill_stride};
+    STK stk{s_stack + threadIdx.x, spill, q, spill_stride};
     int path = -1;
     if (q < n_rays) {
         path = q < n_cam ? cam_q[q] : mat_q[q - n_cam];
@@ -594,7 +602,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_extend_direct(SceneView sc, const 
     if (q < n) {
         if (STRIDE == 4) ray_init(r, F3(((const float4*)o)[q]), F3(((const float4*)d)[q]), sc.tlas_root);
         else ray_init(r, F3(o[3 * (int64_t)q], o[3 * (int64_t)q + 1], o[3 * (int64_t)q + 2]), F3(d[3 * (int64_t)q], d[3 * (int64_t)q + 1], d[3 * (int64_t)q + 2]), sc.tlas_root);
-        Stack<PT_LDS_STACK, PT_BLOCK> stk{s_stack + threadIdx.x, spill + q, spill_stride};
+        Stack<PT_LDS_STACK, PT_BLOCK> stk{s_stack + threadIdx.x, spill, q, spill_stride};
         while (trav_step<true, Stack<PT_LDS_STACK, PT_BLOCK>, WIDE>(sc, r, stk)) {}
         trav_finish<true>(sc, r);
         if (hit_obj) hit_obj[q] = r.hit_obj;
