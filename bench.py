@@ -207,10 +207,14 @@ def main():
             out["other_mode"] = other_mode_pass(pta, gpu, args, w, h, spp, img, args.fast)
             out["tolerance_mode_full_check"] = full_check_pass(pta, gpu, args, w, h, spp)
         if not args.no_extras:
-            out["roofline"] = roofline_pass(pta, dev, scene, desc, args, w, h, spp)
+            out["roofline"] = roofline_block(pta, dev, scene, desc, args, w, h, spp, pt, elapsed / args.steps * 1e3)
             out["reference_pool_shape"] = reference_shape_pass(pta, dev, scene, desc, w, h, spp)
             if args.config != "cornell" and not args.fast:
                 out["also"] = {"cornell": other_config_pass(pta, gpu, "cornell", args)}
+                # the headline workload moved from configs[1] (round 1) to configs[2] (round 2 on): both figures side by side, with the earlier rounds' driver records
+                out["configs1_cornell_Mrays_per_s"] = out["also"]["cornell"]["Mrays_per_s"]
+                out["previous_rounds"] = {"BENCH_r01 (headline = configs[1] cornell)": 12904.9, "BENCH_r02 (headline = configs[2] sphere)": 6182.0,
+                                          "note": "compare value with r02's and configs1_cornell_Mrays_per_s with r01's"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pta, desc, w, h, args.cpu_spp, args.paths)
         print(json.dumps(out), flush=True)
@@ -229,11 +233,17 @@ def single_pool(pta, dev, scene, desc, w, h, spp, paths):
     return d2, pt
 
 
-def roofline_pass(pta, dev, scene, desc, args, w, h, spp):
-    """The extend kernel by itself: one pool (nothing overlaps its launches), one render that counts the algorithmic bytes
-    (counting variant, exact per-ray visit counts), then one render with HIP events on the launch stream around every extend
-    launch.  Which ceiling binds is decided from the committed PMC passes of this same pool shape
-    (profiles/roofline_<config>_1x<paths>.json, tools/pmc_passes.sh + tools/pmc_roofline.py): counters cannot be read inside a timed run."""
+def pmc_file(args, pools, paths):
+    f = os.path.join(ROOT, "profiles", f"roofline_{args.config}_{pools}x{paths}{'_fast' if args.fast else ''}.json")
+    return f, (json.load(open(f)) if os.path.exists(f) else None)
+
+
+def exclusive_pass(pta, dev, scene, desc, args, w, h, spp):
+    """The extend kernel by itself: ONE pool (nothing overlaps its launches), one render that counts the algorithmic bytes (counting
+    variant, exact per-ray visit counts), then one render with HIP events on the launch stream around EVERY extend launch -- the
+    contract's per-launch figure, which a kernel trace of the same command must reproduce (rocprof_avg_launch_us).  The counter-side
+    ceilings come from the committed PMC passes of this pool shape (profiles/roofline_<config>_1x<paths>.json, tools/pmc_passes.sh +
+    tools/pmc_roofline.py): counters cannot be read inside a timed run."""
     paths = args.roofline_paths
     d2, pt = single_pool(pta, dev, scene, desc, w, h, spp, paths)
     try:
@@ -245,52 +255,82 @@ def roofline_pass(pta, dev, scene, desc, args, w, h, spp):
     avg_s = ext_ms / 1e3 / max(timed, 1)
     alg_bytes = rs_c.traversal_bytes / max(launches, 1)
     alg_gbs = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
-    f = os.path.join(ROOT, "profiles", f"roofline_{args.config}_1x{paths}{'_fast' if args.fast else ''}.json")
-    pmc = json.load(open(f)) if os.path.exists(f) else None
-    ceilings = {"hbm_algorithmic": {"achieved": round(alg_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_gbs / HBM_PEAK_GBS, 4),
-                                    "what": "SURVEY 8d bytes (44 + 64 n_inner + 48 n_leaf + 128 (n_enter + n_leave) per ray, exact counts) / launch time: what HBM would have to "
-                                            "deliver if no cache held a node"}}
-    traffic = None
-    if pmc:
-        traffic = pmc["hbm_bytes_per_launch"]
-        t_gbs = traffic / (pmc["rocprof_avg_launch_us"] * 1e-6) / 1e9
-        ceilings["hbm_traffic"] = {"achieved": round(t_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(t_gbs / HBM_PEAK_GBS, 4),
-                                   "what": "bytes that crossed the L2's memory side (TCC_EA0_RDREQ by size + WRITE_SIZE) / the profiled launch time"}
-        if "valu_cycles_per_inst" in pmc and avg_s > 0:
-            # instructions (committed counter pass of this pool shape) x their measured issue cost / the SIMD cycles of the launch as timed HERE
-            clock_hz = pmc["gpu_clock_ghz"] * 1e9
-            busy = pmc["valu_insts_per_launch"] * pmc["valu_cycles_per_inst"] / (1024 * avg_s * clock_hz)
-            ceilings["valu"] = {"achieved": round(busy, 4), "peak": 1.0, "unit": "share of SIMD cycles issuing VALU instructions", "frac": round(busy, 4),
-                                "counter_active_share": round(pmc["valu_busy"], 4),
-                                "what": f"{pmc['valu_insts_per_launch'] / 1e6:.1f} M VALU instructions per launch (SQ_INSTS_VALU) x {pmc['valu_cycles_per_inst']} cycles, the mean "
-                                        "measured issue cost of the traversal loop's instruction mix (tools/valu_mix.py, ubench table) / (1024 SIMDs x launch time x clock), "
-                                        "idle tail included.  counter_active_share = SQ_ACTIVE_INST_VALU * 4 / SIMD cycles, which overstates: it passes 1 when "
-                                        "instructions are added (profiles/r02_valu_sensitivity_sphere.txt: +22 % instructions cost +9 % launch time)"}
-        else:
-            ceilings["valu"] = {"achieved": round(pmc["valu_busy"], 4), "peak": 1.0, "unit": "share of SIMD cycles with a VALU instruction active", "frac": round(pmc["valu_busy"], 4),
-                                "what": "SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * GRBM_GUI_ACTIVE / 8) over the whole launch, idle tail included; "
-                                        f"{pmc['valu_insts_per_launch'] / 1e6:.1f} M VALU instructions per launch"}
-    # the binding ceiling: the physical one the kernel is closest to -- bytes that really crossed the memory side of the L2, or VALU
-    # issue.  hbm_algorithmic (the contract's bytes: every node record a ray consumes, priced as if it came from HBM) passes 1
-    # whenever the caches serve the nodes, so it is printed beside them and binds only when no counter pass is committed.
-    cand = {k: v for k, v in ceilings.items() if k != "hbm_algorithmic"} or ceilings
-    bound = max(cand, key=lambda k: cand[k]["frac"])
-    b = ceilings[bound]
-    res = {"kernel": "k_extend_queue", "bound": {"hbm_algorithmic": "hbm", "hbm_traffic": "hbm", "valu": "valu"}[bound], "ceiling": bound,
-           "achieved": b["achieved"], "peak": b["peak"], "unit": b["unit"], "frac": b["frac"], "traffic": traffic,
-           "algorithmic_frac": ceilings["hbm_algorithmic"]["frac"],
-           "timing": f"exclusive pass after the timed region: 1 pool of {paths} slots (launches of one pool never overlap), HIP events on the launch stream around every launch",
+    f, pmc = pmc_file(args, 1, paths)
+    res = {"shape": f"1 pool of {paths} slots: launches never overlap; HIP events on the launch stream around every extend launch",
+           "hbm_algorithmic": {"achieved": round(alg_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_gbs / HBM_PEAK_GBS, 4),
+                               "what": "SURVEY 8d: algorithmic bytes per launch / average launch duration"},
            "avg_launch_us": round(avg_s * 1e6, 3), "launches_per_render": launches, "launches_timed": int(timed),
            "kernel_time_per_render_ms": round(avg_s * launches * 1e3, 3), "render_ms": round(sec * 1e3, 3),
-           "Mrays_per_s": round(rays / sec / 1e6, 3), "algorithmic_bytes_per_launch": round(alg_bytes, 1),
-           "ceilings": ceilings}
+           "Mrays_per_s": round(rays / sec / 1e6, 3), "algorithmic_bytes_per_launch": round(alg_bytes, 1)}
     if pmc:
+        t_gbs = pmc["hbm_bytes_per_launch"] / (pmc["rocprof_avg_launch_us"] * 1e-6) / 1e9
+        res["hbm_traffic"] = {"achieved": round(t_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(t_gbs / HBM_PEAK_GBS, 4), "bytes_per_launch": pmc["hbm_bytes_per_launch"],
+                              "what": "bytes that crossed the L2's memory side (TCC_EA0_RDREQ by size + WRITE_SIZE) / the profiled launch time"}
+        if "valu_cycles_per_inst" in pmc and avg_s > 0:
+            busy = pmc["valu_insts_per_launch"] * pmc["valu_cycles_per_inst"] / (1024 * avg_s * pmc["gpu_clock_ghz"] * 1e9)
+            res["valu_issue_MODELLED"] = {"frac": round(busy, 4), "counter_active_share": round(pmc["valu_busy"], 4),
+                                          "what": f"MODELLED, not measured in the run: {pmc['valu_insts_per_launch'] / 1e6:.1f} M VALU instructions per launch (SQ_INSTS_VALU, committed counter pass) x "
+                                                  f"{pmc['valu_cycles_per_inst']} cycles, the mean issue cost of the traversal loop's instruction mix from a microbenchmark table (tools/valu_mix.py, "
+                                                  "profiles/r01_ubench_issue_rates_gfx950.txt) / (1024 SIMDs x launch time x clock), idle tail included.  counter_active_share = "
+                                                  "SQ_ACTIVE_INST_VALU * 4 / SIMD cycles is the raw counter; it overstates (it passes 1 when instructions are added, profiles/r02_valu_sensitivity_sphere.txt)"}
         res.update({"rocprof_avg_launch_us": pmc["rocprof_avg_launch_us"], "occupancy": pmc["occupancy"], "l1_hit": pmc["l1_hit"], "l2_hit": pmc["l2_hit"],
                     "wait_on_data_share_of_wave_time": pmc["wait_on_data_share_of_wave_time"],
                     "sources": [os.path.relpath(f, ROOT)] + [f"profiles/{s}" for s in pmc["sources"]]})
     else:
         res["sources"] = []
-        res["note"] = f"no committed PMC passes for this pool shape ({os.path.relpath(f, ROOT)} absent): only the algorithmic ceiling is known"
+        res["note"] = f"no committed PMC passes for this pool shape ({os.path.relpath(f, ROOT)} absent): only the algorithmic figure is known"
+    return res
+
+
+def roofline_block(pta, dev, scene, desc, args, w, h, spp, pt, ms_per_step):
+    """`roofline` for the SHAPE THAT IS TIMED: SURVEY 8d's algorithmic bytes against the HBM peak.  With several pools in flight the
+    extend launches of different pools overlap, so a launch's own duration (events) includes the time it shares the chip: the figure
+    that describes the chip is the render's -- all algorithmic bytes of the render / the render's wall time -- and that is `frac`.  The
+    literal per-launch figure is printed for the timed shape (events around one launch in sixteen of a further render) and for an
+    exclusive one-pool pass, and the cross-check kernel time <= wall time x overlap depth is printed, not implied."""
+    pools = getattr(pt, "pools", [pt])
+    pt.reset()
+    rs_c = pt.run(count_bytes=True)                      # counting variant: exact visit counts; deterministic render => the timed renders' bytes
+    n_launches = sum(int(r.steps) for r in getattr(pt, "last_pool_stats", [rs_c]))
+    pt.reset()
+    import torch
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    rs_t = pt.run(time_extend=True)                      # events around one extend launch in sixteen, per pool
+    torch.cuda.synchronize(); wall_ev = time.perf_counter() - t0
+    avg_ov_s = rs_t.extend_ms / 1e3 / max(rs_t.extend_launches, 1)
+    wall_s = ms_per_step / 1e3
+    alg = float(rs_c.traversal_bytes)
+    gbs = alg / wall_s / 1e9
+    f, pmc = pmc_file(args, len(pools), args.paths)
+    kernel_s = avg_ov_s * n_launches
+    res = {"kernel": "k_extend_queue", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+           "traffic": pmc["hbm_bytes_per_launch"] if pmc else None,
+           "shape": f"the timed shape: {len(pools)} pool(s) of {args.paths} slots, launches of different pools overlap",
+           "what": "achieved = SURVEY 8d algorithmic bytes of ALL extend launches of one render (44 + 64 n_inner + 48 n_leaf + 128 (n_enter + n_leave) per ray, exact "
+                   "counts) / ms_per_step: what HBM would have to deliver if no cache held a node.  traffic = HBM bytes per launch from the committed counter passes of this shape",
+           "algorithmic_bytes_per_render": alg, "extend_launches_per_render": n_launches, "algorithmic_bytes_per_launch": round(alg / max(n_launches, 1), 1),
+           "per_launch_in_the_timed_shape": {"avg_launch_us": round(avg_ov_s * 1e6, 3), "launches_timed": int(rs_t.extend_launches),
+                                             "hbm_algorithmic_frac": round(alg / max(n_launches, 1) / avg_ov_s / 1e9 / HBM_PEAK_GBS, 4) if avg_ov_s > 0 else None,
+                                             "what": "the contract's literal formula; a launch shares the chip with the other pools' launches for most of its duration"},
+           "kernel_time_per_render_ms": round(kernel_s * 1e3, 3), "ms_per_step": round(ms_per_step, 3), "overlap_depth": round(kernel_s / wall_s, 3),
+           "cross_check": f"sum of extend launch durations {kernel_s * 1e3:.1f} ms = ms_per_step {ms_per_step:.1f} x overlap depth {kernel_s / wall_s:.2f} "
+                          f"(<= {len(pools)} pools); the render with events took {wall_ev * 1e3:.1f} ms"}
+    if pmc:
+        t_gbs = pmc["hbm_bytes_per_launch"] * n_launches / wall_s / 1e9
+        res["hbm_traffic"] = {"achieved": round(t_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(t_gbs / HBM_PEAK_GBS, 4),
+                              "what": "counter bytes per launch (committed passes of this shape) x launches per render / ms_per_step"}
+        res.update({"rocprof_avg_launch_us": pmc["rocprof_avg_launch_us"], "occupancy": pmc["occupancy"], "l1_hit": pmc["l1_hit"], "l2_hit": pmc["l2_hit"],
+                    "sources": [os.path.relpath(f, ROOT)] + [f"profiles/{s}" for s in pmc["sources"]]})
+    else:
+        res["sources"] = []
+    res["exclusive"] = exclusive_pass(pta, dev, scene, desc, args, w, h, spp)
+    ex = res["exclusive"]
+    physical = {k: ex[k]["frac"] for k in ("hbm_traffic", "valu_issue_MODELLED") if k in ex}
+    if physical:
+        top = max(physical, key=physical.get)
+        res["closest_physical_ceiling"] = {"name": top, "frac": physical[top],
+                                           "what": "of the ceilings other than the contract's algorithmic one, the one the exclusive launch is closest to; hbm_algorithmic prices every node "
+                                                   "record as if it came from HBM and passes 1 whenever the caches serve the nodes"}
     return res
 
 
@@ -391,7 +431,11 @@ def cpu_baseline(pta, desc, w, h, spp, paths):
     spp reduced.  The reference's own WGSL needs a WebGPU adapter, which this image does not have."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
-    threads = min(16, os.cpu_count() or 1)
+    # every host core this process may use: the affinity mask, and the thread cap the box sets for its one-GPU share (OMP_NUM_THREADS = 16
+    # there; os.cpu_count() shows the whole machine, many times that, most of it other tenants')
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cap = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    threads = min(usable, cap) if cap > 0 else usable
     s = orc.OrcScene(desc)
     r = orc.OrcRender(s, w, h, desc["camera"], spp, paths, ext=desc.get("settings"))
     t0 = time.perf_counter()
@@ -399,6 +443,7 @@ def cpu_baseline(pta, desc, w, h, spp, paths):
     dt = time.perf_counter() - t0
     webgpu = "UNAVAILABLE (no WebGPU adapter)"
     return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "cores_note": f"threads used = min(cores in this process's affinity mask: {usable}, OMP_NUM_THREADS: {cap or 'unset'}); os.cpu_count() = {os.cpu_count()}",
             "sample": f"same scene and camera at {w}x{h}, {spp} spp (bounded sample), {paths} slots: {rays} rays in {dt:.1f} s",
             "reference_wgsl_on_software_adapter": webgpu}
 
