@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the exclusive roofline pass, the reference-shaped pool and the configs[1] render")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=32, help="spp of the bounded CPU-baseline sample")
+    ap.add_argument("--strong", action="store_true", help="N > 1: split the config's spp N ways (fixed total work, 'scaling': 'strong') instead of giving every GPU the full spp")
+    ap.add_argument("--lib-comm", action="store_true", help="N > 1: sum the accumulation buffers with the library's own RCCL reduce (pt_comm_create_rank / pt_comm_reduce_image) "
+                                                             "instead of torch.distributed's")
     ap.add_argument("--png", default="", help="write the tonemapped frame of the last step here (rank 0)")
     args = ap.parse_args()
 
@@ -133,7 +136,11 @@ def main():
 
     # per-GPU share: full spp each, distinct ticket range and RNG streams
     image = torch.zeros(h * w * 4, dtype=torch.float32, device="cuda")
-    settings = pta.multigpu.weak_share(rank, world, w, h, spp, args.paths, pools=args.pools)
+    if args.strong and (spp % world or (spp // world) % 8):
+        raise SystemExit(f"--strong: {spp} spp do not split into {world} shares of whole pixel tickets (8 samples each, logic.js:6)")
+    share = pta.multigpu.strong_share if args.strong else pta.multigpu.weak_share
+    settings = share(rank, world, w, h, spp, args.paths, pools=args.pools)
+    spp_total = spp if args.strong else spp * world
     settings["imageDev"] = image.data_ptr()
     settings.update(desc.get("settings", {}))       # a scene's extension materials and bounce cut
     pt = pta.init_path_tracer({"device": dev, "scene": scene, "image": {"width": w, "height": h}, "camera": desc["camera"], "settings": settings})
@@ -143,18 +150,35 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    lib_comm = None
+    if world > 1 and args.lib_comm:                            # the library's communicator: rank 0 makes the id, torch.distributed only carries it
+        ident = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            ident.copy_(torch.frombuffer(bytearray(pta.multigpu.LibComm.unique_id().raw), dtype=torch.uint8))
+        dist.broadcast(ident, src=0)
+        import ctypes
+        lib_comm = pta.multigpu.LibComm([dev], id128=ctypes.create_string_buffer(bytes(ident.cpu().numpy().tobytes()), 128), rank=rank, world=world)
+    reduce_s, render_s = [], []
+
     def one_step():
         pt.reset()
-        rs = pt.run()
-        pta.multigpu.reduce_image(image, dst=0)                # RCCL over xGMI: W*H*4 floats (no-op at N=1)
+        t_a = time.perf_counter()
+        rs = pt.run()                                          # returns when this GPU's render has finished
+        t_b = time.perf_counter()
+        if lib_comm is not None:
+            lib_comm.reduce_image(0)                           # ncclReduce on the context's stream, waited for
+        else:
+            pta.multigpu.reduce_image(image, dst=0)            # RCCL over xGMI: W*H*4 floats (no-op at N=1)
         if world > 1:
             # The reduce runs on RCCL's own stream; the next render's reset zeroes this same buffer from the pools' streams.
             # Make the order explicit instead of leaning on NULL-stream semantics: the host waits for the reduce.
             torch.cuda.synchronize()
+        render_s.append(t_b - t_a); reduce_s.append(time.perf_counter() - t_b)
         return rs
 
     for _ in range(args.warmup):
         one_step()
+    del reduce_s[:], render_s[:]
     barrier()
     t0 = time.perf_counter()
     rays = samples = wasted = checked = mismatched = flipped = beyond = lost = 0
@@ -176,9 +200,25 @@ def main():
         elapsed = float(tmax[0])
     all_rays, all_samples, all_wasted = float(tot[1]), float(tot[2]), float(tot[3])
 
+    ranks_report = None
+    if world > 1:
+        # what makes an N-GPU record verifiable: the world size the communicator reports, and per rank the physical device, its own rays,
+        # render time and reduce time (the reduce includes waiting for the slowest rank)
+        import ctypes
+        bus = ctypes.create_string_buffer(64)
+        dev.call("pt_device_pci_bus_id", bus, 64)
+        mine = {"rank": rank, "local_rank": local_rank, "device_index": gpu, "pci_bus_id": bus.value.decode(), "device_name": torch.cuda.get_device_name(gpu),
+                "rays": int(rays), "render_ms_mean": round(1e3 * sum(render_s) / max(len(render_s), 1), 3), "reduce_ms_mean": round(1e3 * sum(reduce_s) / max(len(reduce_s), 1), 3),
+                "Mrays_per_s_of_its_own_renders": round(rays / max(sum(render_s), 1e-9) / 1e6, 3), "slot_base": settings["slotBase"],
+                "tickets": [settings["ticketBegin"], settings["ticketEnd"]]}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        ranks_report = {"world_size_seen_by_the_communicator": dist.get_world_size(), "backend": dist.get_backend(),
+                        "reduce": "pt_comm_reduce_image (library, RCCL)" if lib_comm is not None else f"torch.distributed.reduce ({dist.get_backend()}; nccl = RCCL)", "ranks": gathered,
+                        "distinct_devices": len({g["pci_bus_id"] for g in gathered})}
     if rank == 0:
         img = image.cpu().numpy().reshape(h, w, 4)
-        assert np.all(img[..., 3] == spp * world), "every pixel must have received exactly spp samples"
+        assert np.all(img[..., 3] == spp_total), f"every pixel must have received exactly {spp_total} samples (image .w = spp x world)"
         if args.png:
             disp = pta.init_display({"device": dev, "canvas": args.png, "image": {"buffer": image.data_ptr(), "width": w, "height": h}})
             disp.draw()
@@ -189,10 +229,11 @@ def main():
         out = {
             "metric": "Mrays/s", "value": round(all_rays / elapsed / 1e6, 3), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[{cfg_index}] {args.config}: {info.n_tris} tris / {info.n_objects} instances, {w}x{h}, {spp} spp per GPU, "
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[{cfg_index}] {args.config}: {info.n_tris} tris / {info.n_objects} instances, {w}x{h}, {spp // world if args.strong else spp} spp per GPU, "
                                    f"{args.pools} pool(s) of {args.paths} path slots (reference: 1 pool of 1000000), {rules}{mode}",
-                       "spp_total": spp * world, "parallelism": f"spp-split x{world}, RCCL sum-reduce of the accumulation buffer"},
+                       "spp_total": spp_total, "parallelism": f"spp-split x{world} ({'strong: the spp are divided' if args.strong else 'weak: every GPU renders the full spp'}), "
+                                                                 "RCCL sum-reduce of the accumulation buffer"},
             "samples_per_s": round(all_samples / elapsed, 1),
             "rays_per_render_per_gpu": rays // args.steps, "wavefront_iterations_per_render": int(steps_per_render),
             # slots that ticket exhaustion has just retired are still pushed to the camera queue and trace one last ray
@@ -200,6 +241,9 @@ def main():
             "wasted_rays_per_render_per_gpu": wasted // args.steps, "useful_Mrays_per_s": round((all_rays - all_wasted) / elapsed / 1e6, 3),
             "scene_build_s": round(build_s, 3),
         }
+        if ranks_report:
+            out["multi_gpu"] = ranks_report
+            out["multi_gpu"]["image_check"] = f"every pixel of the reduced image holds exactly {spp_total} samples: asserted"
         if args.fast:
             out["tolerance_check"] = {"rays_rewalked_exactly": checked, "different_hit": mismatched, "hit_vs_miss": flipped, "beyond_1e-6": beyond, "of_those_reference_hit_lost": lost, "max_rel_hit_dist_diff": max_rel,
                                       "share_rewalked": round(checked / max(rays, 1), 5)}
@@ -218,6 +262,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pta, desc, w, h, args.cpu_spp, args.paths)
         print(json.dumps(out), flush=True)
+    if lib_comm is not None:
+        lib_comm.destroy()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

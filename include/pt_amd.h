@@ -56,6 +56,8 @@ const char* pt_last_error(const pt_ctx* ctx);
 /* Optional: run all work on a caller-owned hipStream_t (e.g. torch's current stream). NULL = own stream. */
 int         pt_set_stream(pt_ctx* ctx, void* hip_stream);
 int         pt_sync(pt_ctx* ctx);
+/* "0000:c1:00.0"-style PCI bus id of the ctx's GPU (hipDeviceGetPCIBusId): lets a multi-GPU host print which physical device each rank drives. */
+int         pt_device_pci_bus_id(pt_ctx* ctx, char* out, size_t cap);
 
 /* ---- scene (scripts/scene) ---- */
 /* replaces: scene.registerMesh({file}) (scene.js:518-521) after parseObj (builders.js:155):
@@ -216,8 +218,13 @@ int pt_queue_read(pt_ctx* ctx, int which, int32_t* out, int64_t* n_io);
  * Samples are independent, so a render shards with no exchange on the data path: every GPU holds the whole scene and renders
  * its own pixel-ticket range with its own RNG streams (pt_render_params.slot_base / ticket_begin / ticket_end), into its own
  * accumulation buffer.  The ONE collective is the sum of those buffers: pt_comm_reduce_image = RCCL ncclReduce(sum, float32,
- * W*H*4) over xGMI onto rank `root`'s image, in place, ordered behind the renders on the contexts' streams, waited for.
+ * W*H*4) over xGMI onto rank `root`'s image, in place, ordered behind the work on the contexts' streams, waited for.
  * The image is sums of radiance and sample counts (logic.js:146-149), so the sum has the single-GPU image's form.
+ * The reduce MOVES the samples: afterwards the root's image holds every rank's samples and every other rank's image is zero, so it
+ * may be called again later in the same render (a progressive refresh) and adds only what has been accumulated since -- nothing is
+ * counted twice.  It knows only the communicator's own contexts: pools made by pt_create_sharing_scene that add into the same images
+ * must have finished (pt_render_run / pt_render_run_many return finished; after pt_render_step: pt_sync) and, in the middle of a
+ * render, have had their open pixel tickets flushed (pt_image_flush + pt_sync) before the call.
  *   pt_comm_create        one process drives several GPUs: ctxs[i] is rank i (one context per GPU; ncclCommInitAll)
  *   pt_comm_unique_id +   one process per GPU: rank 0 makes the 128-byte id, the host passes it to the other ranks by its own
  *   pt_comm_create_rank   means (environment, file, torch.distributed store), every rank joins with its context (ncclCommInitRank)

@@ -62,6 +62,7 @@ SIGNATURES = {
     "pt_last_error": (C.c_char_p, [C.c_void_p]),
     "pt_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pt_sync": (C.c_int, [C.c_void_p]),
+    "pt_device_pci_bus_id": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     "pt_mesh_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "pt_scene_build": (C.c_int, [C.c_void_p, C.POINTER(PtInstance), C.c_int]),
     "pt_scene_get_info": (C.c_int, [C.c_void_p, C.POINTER(PtSceneInfo)]),

@@ -2,7 +2,7 @@
 // (registerMesh x k -> instanceMesh x m -> build -> initPathTracer -> loop { step } -> display) in C++ over the C ABI.
 //
 //   pt_cli [--obj FILE]... [--instance MESH,px,py,pz,rx,ry,rz,sx,sy,sz,MATERIAL]... [--camera px,py,pz,lx,ly,lz,fov]
-//          [--width W] [--height H] [--samples S] [--paths N] [--pools K] [--device D] [--gpus G] [--progress K] [--out frame.png|frame.ppm] [--json]
+//          [--width W] [--height H] [--samples S] [--paths N] [--pools K] [--device D] [--gpus G] [--progress K] [--traversal reference|tolerance|auto] [--out frame.png|frame.ppm] [--json]
 //          [--material TYPE,r,g,b[,e0,e1,e2]]... [--max-nb N] [--seed S]      extensions (material ids 2, 3, ...; TYPE lambert|emitter|mirror|glossy)
 // --gpus G: the samples are split over GPUs 0..G-1 of this node -- every GPU gets the scene, its own RNG streams and the
 // g-th part of the pixel tickets -- and the accumulation buffers are summed onto GPU 0 by one RCCL reduce (pt_comm_reduce_image).
@@ -102,7 +102,7 @@ static int dump_host(const std::string& file, const std::string& trs) {
 int main(int argc, char** argv) {
     std::vector<std::string> objs, insts; std::string cam, out; bool json = false;
     int width = 512, height = 512, samples = 16, paths = 0, device = 0, progress = 0, pools = 1, gpus = 1;
-    pt_render_ext ext; memset(&ext, 0, sizeof ext); bool have_ext = false;
+    pt_render_ext ext; memset(&ext, 0, sizeof ext); bool have_ext = false; int traversal = PT_TRAVERSAL_REFERENCE;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto next = [&]() -> std::string { return i + 1 < argc ? argv[++i] : ""; };
@@ -130,6 +130,8 @@ int main(int argc, char** argv) {
             for (int k = 0; k < 3; k++) { m.albedo[k] = (float)v[k]; m.emission[k] = (float)v[3 + k]; }     // glossy: e0 = roughness
             have_ext = true;
         }
+        else if (a == "--traversal") { std::string m = next(); traversal = m == "reference" ? PT_TRAVERSAL_REFERENCE : m == "tolerance" ? PT_TRAVERSAL_WIDE : m == "auto" ? PT_TRAVERSAL_AUTO : -1;
+                                        if (traversal < 0) { fprintf(stderr, "--traversal reference|tolerance|auto\n"); return 2; } }
         else if (a == "--progress") progress = atoi(next().c_str());
         else if (a == "--out") out = next();
         else if (a == "--json") json = true;
@@ -150,6 +152,7 @@ int main(int argc, char** argv) {
     for (int g = 0; g < gpus; g++) {
         pt_ctx* cg = nullptr;
         { int rc_ = pt_create(device + g, &cg); if (rc_ < 0) { fprintf(stderr, "pt_create(%d) failed (%d): %s\n", device + g, rc_, pt_last_error(nullptr)); return 1; } }
+        if (traversal != PT_TRAVERSAL_REFERENCE && pt_set_traversal_mode(cg, traversal) < 0) { fprintf(stderr, "pt_set_traversal_mode: %s\n", pt_last_error(cg)); return 1; }
         if (g == 0) ctx = cg;
         gpu_ctx.push_back(cg);
         for (const ParsedObj& p : parsed) {                                       // registerMesh (scene.js:518), once per GPU: the scene is replicated

@@ -434,6 +434,12 @@ int pt_set_stream(pt_ctx* c, void* hip_stream) {
     return PT_OK;
 }
 
+int pt_device_pci_bus_id(pt_ctx* c, char* out, size_t cap) {
+    if (!c || !out || cap < 16) return fail(c, PT_ERR_ARG, "pt_device_pci_bus_id: bad argument");
+    HIPOK(c, hipDeviceGetPCIBusId(out, (int)cap, c->device));
+    return PT_OK;
+}
+
 int pt_sync(pt_ctx* c) {
     if (!c) return PT_ERR_ARG;
     HIPOK(c, hipSetDevice(c->device));

@@ -33,10 +33,78 @@ struct Rccl {
 Rccl g_rccl;
 std::mutex g_rccl_mutex;
 
+// ---- loopback backend (PT_COMM_LOOPBACK=1 in the environment when the first communicator is made) ----------------------------------
+// The same eight entry points for "ranks" that are contexts of ONE process, summed by a kernel of this file instead of RCCL.  It exists
+// so that the semantics of pt_comm_reduce_image at world size > 1 -- what ends up where, what a second reduce adds -- can be tested on
+// a box with one GPU (RCCL refuses two ranks on one device).  It is not a fallback: nothing selects it but that variable.
+struct LoopOp { const float* send; float* recv; size_t count; int root, rank; hipStream_t stream; };
+struct LoopWorld { int world = 0; std::vector<LoopOp> pending; };
+struct LoopComm { LoopWorld* w; int rank; int device; };
+thread_local bool g_loop_grouped = false;
+thread_local std::vector<LoopComm*> g_loop_touched;
+
+__global__ void k_loop_sum(float* __restrict__ recv, const float* const* __restrict__ sends, int n, size_t count) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float acc = sends[0][i];
+    for (int k = 1; k < n; k++) acc += sends[k][i];               // rank order: a fixed order, like a ring's
+    recv[i] = acc;
+}
+ncclResult_t loop_flush(LoopWorld* w) {
+    if ((int)w->pending.size() != w->world) return ncclInvalidUsage;     // every rank of the communicator takes part in a reduce
+    std::vector<const float*> sends((size_t)w->world); const LoopOp* root = nullptr;
+    for (const LoopOp& op : w->pending) { sends[(size_t)op.rank] = op.send; if (op.rank == op.root) root = &op; if (hipStreamSynchronize(op.stream) != hipSuccess) return ncclUnhandledCudaError; }
+    if (!root) return ncclInvalidArgument;
+    const float** d_ptrs = nullptr;
+    if (hipMalloc((void**)&d_ptrs, sends.size() * sizeof(float*)) != hipSuccess) return ncclUnhandledCudaError;
+    (void)hipMemcpy(d_ptrs, sends.data(), sends.size() * sizeof(float*), hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_loop_sum, dim3((unsigned)((root->count + 255) / 256)), dim3(256), 0, root->stream, root->recv, d_ptrs, w->world, root->count);
+    hipError_t e = hipStreamSynchronize(root->stream);
+    (void)hipFree(d_ptrs);
+    w->pending.clear();
+    return e == hipSuccess ? ncclSuccess : ncclUnhandledCudaError;
+}
+ncclResult_t loop_GetUniqueId(ncclUniqueId* id) { memset(id, 0, sizeof *id); return ncclSuccess; }
+ncclResult_t loop_CommInitRank(ncclComm_t* out, int world, ncclUniqueId, int rank) {
+    if (world != 1) return ncclInvalidUsage;                              // ranks in other processes need the real thing
+    LoopWorld* w = new LoopWorld(); w->world = 1;
+    *out = (ncclComm_t) new LoopComm{w, rank, 0};
+    return ncclSuccess;
+}
+ncclResult_t loop_CommInitAll(ncclComm_t* out, int n, const int* devs) {
+    LoopWorld* w = new LoopWorld(); w->world = n;
+    for (int i = 0; i < n; i++) out[i] = (ncclComm_t) new LoopComm{w, i, devs[i]};
+    return ncclSuccess;
+}
+ncclResult_t loop_CommDestroy(ncclComm_t c) { LoopComm* lc = (LoopComm*)c; if (lc->rank == 0) delete lc->w; delete lc; return ncclSuccess; }
+ncclResult_t loop_GroupStart() { g_loop_grouped = true; g_loop_touched.clear(); return ncclSuccess; }
+ncclResult_t loop_Reduce(const void* send, void* recv, size_t count, ncclDataType_t t, ncclRedOp_t op, int root, ncclComm_t c, hipStream_t stream) {
+    if (t != ncclFloat32 || op != ncclSum) return ncclInvalidArgument;
+    LoopComm* lc = (LoopComm*)c;
+    lc->w->pending.push_back({(const float*)send, (float*)recv, count, root, lc->rank, stream});
+    if (g_loop_grouped) { g_loop_touched.push_back(lc); return ncclSuccess; }
+    return loop_flush(lc->w);
+}
+ncclResult_t loop_GroupEnd() {
+    g_loop_grouped = false;
+    ncclResult_t r = ncclSuccess;
+    if (!g_loop_touched.empty()) r = loop_flush(g_loop_touched[0]->w);
+    g_loop_touched.clear();
+    return r;
+}
+const char* loop_GetErrorString(ncclResult_t r) { return r == ncclSuccess ? "ok" : "loopback backend: invalid use (a reduce needs every rank of its communicator)"; }
+bool g_loopback = false;
+
 bool load_rccl(std::string& why) {
     std::lock_guard<std::mutex> lock(g_rccl_mutex);
     if (g_rccl.so) return true;
     if (!g_rccl.error.empty()) { why = g_rccl.error; return false; }
+    if (const char* e = getenv("PT_COMM_LOOPBACK"); e && e[0] == '1') {       // test backend, see above
+        g_rccl.GetUniqueId = loop_GetUniqueId; g_rccl.CommInitRank = loop_CommInitRank; g_rccl.CommInitAll = loop_CommInitAll; g_rccl.CommDestroy = loop_CommDestroy;
+        g_rccl.Reduce = loop_Reduce; g_rccl.GroupStart = loop_GroupStart; g_rccl.GroupEnd = loop_GroupEnd; g_rccl.GetErrorString = loop_GetErrorString;
+        g_rccl.so = (void*)&g_rccl; g_loopback = true;
+        return true;
+    }
     void* so = nullptr;
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
         if ((so = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
@@ -101,11 +169,12 @@ int pt_comm_create(pt_ctx** ctxs, int n, pt_comm** out) {
     for (int i = 0; i < n; i++) {
         if (!ctxs[i]) return pt_ctx_fail(nullptr, PT_ERR_ARG, "pt_comm_create: null context");
         devs[(size_t)i] = pt_ctx_device(ctxs[i]);
-        for (int k = 0; k < i; k++)
-            if (devs[(size_t)k] == devs[(size_t)i]) return pt_ctx_fail(ctxs[0], PT_ERR_ARG, "pt_comm_create: two contexts on one GPU (one communicator rank per GPU)");
     }
     std::string why;
     if (!load_rccl(why)) return pt_ctx_fail(ctxs[0], PT_ERR_STATE, why);
+    for (int i = 0; i < n && !g_loopback; i++)
+        for (int k = 0; k < i; k++)
+            if (devs[(size_t)k] == devs[(size_t)i]) return pt_ctx_fail(ctxs[0], PT_ERR_ARG, "pt_comm_create: two contexts on one GPU (one communicator rank per GPU)");
     std::vector<ncclComm_t> comms((size_t)n);
     NCCLOK(ctxs[0], g_rccl.CommInitAll(comms.data(), n, devs.data()));
     pt_comm* c = new pt_comm();
@@ -114,8 +183,13 @@ int pt_comm_create(pt_ctx** ctxs, int n, pt_comm** out) {
     return PT_OK;
 }
 
-// Adds every rank's accumulation buffer onto rank `root`'s, in place, on the contexts' own streams (so it is ordered behind
-// the render that filled them), and waits for the local part.  Every local context must hold a render of the same size.
+// MOVES every rank's accumulation buffer onto rank `root`'s: the root's image becomes the sum of all ranks' images, every other rank's
+// image is zeroed (its samples now live in the root's), so a later reduce -- a progressive refresh in the middle of a render -- adds only
+// what the ranks have accumulated since and counts nothing twice.  Runs on the contexts' own streams (ordered behind the work already
+// on them) and waits for the local part.  Every local context must hold a render of the same size.  The caller has to have finished
+// (pt_render_run / pt_render_run_many return finished; after pt_render_step: pt_sync) every OTHER context that adds into one of these
+// images -- the pools of pt_create_sharing_scene -- and, in the middle of a render, to have flushed their open pixel tickets
+// (pt_image_flush + pt_sync): this call only knows the communicator's own contexts.
 int pt_comm_reduce_image(pt_comm* comm, int root) {
     if (!comm || root < 0 || root >= comm->world) return pt_ctx_fail(comm && !comm->ctxs.empty() ? comm->ctxs[0] : nullptr, PT_ERR_ARG, "pt_comm_reduce_image: bad argument");
     const size_t n = comm->ctxs.size();
@@ -131,12 +205,24 @@ int pt_comm_reduce_image(pt_comm* comm, int root) {
     const size_t count = (size_t)w0 * (size_t)h0 * 4;
     pt_ctx* c0 = comm->ctxs[0];
     NCCLOK(c0, g_rccl.GroupStart());
-    for (size_t i = 0; i < n; i++) {
-        if (hipSetDevice(pt_ctx_device(comm->ctxs[i])) != hipSuccess) return pt_ctx_fail(comm->ctxs[i], PT_ERR_HIP, "pt_comm_reduce_image: hipSetDevice failed");
-        NCCLOK(comm->ctxs[i], g_rccl.Reduce(img[i], img[i], count, ncclFloat32, ncclSum, root, comm->comms[i], pt_ctx_stream(comm->ctxs[i])));
+    // a failure between GroupStart and GroupEnd must still close the group, or this thread's next collective would queue into it
+    int failed = PT_OK; size_t failed_at = 0; std::string failed_msg;
+    for (size_t i = 0; i < n && failed == PT_OK; i++) {
+        if (hipSetDevice(pt_ctx_device(comm->ctxs[i])) != hipSuccess) { failed = PT_ERR_HIP; failed_at = i; failed_msg = "pt_comm_reduce_image: hipSetDevice failed"; break; }
+        ncclResult_t r = g_rccl.Reduce(img[i], img[i], count, ncclFloat32, ncclSum, root, comm->comms[i], pt_ctx_stream(comm->ctxs[i]));
+        if (r != ncclSuccess) { failed = PT_ERR_HIP; failed_at = i; failed_msg = std::string("ncclReduce: ") + g_rccl.GetErrorString(r); }
     }
-    NCCLOK(c0, g_rccl.GroupEnd());
-    for (size_t i = 0; i < n; i++) { int r = pt_sync(comm->ctxs[i]); if (r) return r; }
+    ncclResult_t ge = g_rccl.GroupEnd();
+    if (failed != PT_OK) return pt_ctx_fail(comm->ctxs[failed_at], failed, failed_msg);
+    if (ge != ncclSuccess) return pt_ctx_fail(c0, PT_ERR_HIP, std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(ge));
+    for (size_t i = 0; i < n; i++) {
+        pt_ctx* c = comm->ctxs[i];
+        if (comm->first_rank + (int)i != root) {             // this rank's samples have moved to the root
+            if (hipSetDevice(pt_ctx_device(c)) != hipSuccess || hipMemsetAsync(img[i], 0, count * 4, pt_ctx_stream(c)) != hipSuccess)
+                return pt_ctx_fail(c, PT_ERR_HIP, "pt_comm_reduce_image: clearing a non-root image failed");
+        }
+        int r = pt_sync(c); if (r) return r;
+    }
     return PT_OK;
 }
 

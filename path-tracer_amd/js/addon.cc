@@ -223,6 +223,22 @@ static napi_value RenderStep(napi_env env, napi_callback_info info) {
     set(env, o, "rays", (double)st.n_rays); set(env, o, "step", (double)st.step_index);
     return o;
 }
+// tolerance mode: what the exact re-walks of the sampled rays found (all 0 in the reference-exact mode)
+static void set_check(napi_env env, napi_value o, const pt_run_stats& rs) {
+    set(env, o, "checkedRays", (double)rs.checked_rays); set(env, o, "mismatchedRays", (double)rs.mismatched_rays); set(env, o, "flippedRays", (double)rs.flipped_rays);
+    set(env, o, "maxRelDistDiff", rs.max_rel_dist_diff); set(env, o, "beyondToleranceRays", (double)rs.beyond_tolerance_rays); set(env, o, "lostHitRays", (double)rs.lost_hit_rays);
+}
+// setTraversal(ctx, mode, checkPeriod) -> mode in use once a scene is built, else -1     [pt_set_traversal_mode, pt_set_traversal_check, pt_get_traversal_mode]
+static napi_value SetTraversal(napi_env env, napi_callback_info info) {
+    napi_value a[3]; if (!get_args(env, info, 3, a)) return nullptr;
+    pt_ctx* c = ctx_of(env, a[0]); if (!c) return nullptr;
+    int rc = pt_set_traversal_mode(c, (int)i64(env, a[1]));
+    if (rc < 0) return throw_pt(env, c, "pt_set_traversal_mode", rc);
+    if (i64(env, a[2]) >= 0 && (rc = pt_set_traversal_check(c, (int)i64(env, a[2]))) < 0) return throw_pt(env, c, "pt_set_traversal_check", rc);
+    int used = -1; (void)pt_get_traversal_mode(c, &used);
+    napi_value v; napi_create_int32(env, used, &v);
+    return v;
+}
 // renderRun(ctx, maxSteps, flags) -> stats                                  [pt_render_run]
 static napi_value RenderRun(napi_env env, napi_callback_info info) {
     napi_value a[3]; if (!get_args(env, info, 3, a)) return nullptr;
@@ -233,6 +249,7 @@ static napi_value RenderRun(napi_env env, napi_callback_info info) {
     set(env, o, "steps", (double)rs.steps); set(env, o, "totalRays", (double)rs.total_rays); set(env, o, "totalSamples", (double)rs.total_samples);
     set(env, o, "stackOverflows", (double)rs.stack_overflows); set(env, o, "extendMs", rs.extend_ms);
     set(env, o, "extendLaunches", (double)rs.extend_launches); set(env, o, "traversalBytes", (double)rs.traversal_bytes); set(env, o, "wastedRays", (double)rs.wasted_rays);
+    set_check(env, o, rs);
     return o;
 }
 // renderRunMany([ctx, ...], maxSteps, flags) -> [stats, ...]                [pt_render_run_many]
@@ -250,6 +267,7 @@ static napi_value RenderRunMany(napi_env env, napi_callback_info info) {
         set(env, o, "steps", (double)rs[i].steps); set(env, o, "totalRays", (double)rs[i].total_rays); set(env, o, "totalSamples", (double)rs[i].total_samples);
         set(env, o, "stackOverflows", (double)rs[i].stack_overflows); set(env, o, "extendMs", rs[i].extend_ms);
         set(env, o, "extendLaunches", (double)rs[i].extend_launches); set(env, o, "traversalBytes", (double)rs[i].traversal_bytes); set(env, o, "wastedRays", (double)rs[i].wasted_rays);
+        set_check(env, o, rs[i]);
         napi_set_element(env, arr, i, o);
     }
     return arr;
@@ -312,7 +330,7 @@ static napi_value Init(napi_env env, napi_value exports) {
     struct { const char* name; napi_callback fn; } fns[] = {
         {"create", Create}, {"createSharingScene", CreateSharingScene}, {"renderRunMany", RenderRunMany}, {"destroy", Destroy}, {"meshUpload", MeshUpload}, {"sceneBuild", SceneBuild}, {"sceneInfo", SceneInfo},
         {"readBuffer", ReadBuffer}, {"traceRays", TraceRays}, {"renderInit", RenderInit}, {"renderReset", RenderReset},
-        {"renderSetExtensions", RenderSetExtensions},
+        {"renderSetExtensions", RenderSetExtensions}, {"setTraversal", SetTraversal},
         {"renderStep", RenderStep}, {"renderRun", RenderRun}, {"imageRead", ImageRead}, {"tonemap", Tonemap},
         {"commCreate", CommCreate}, {"commReduceImage", CommReduceImage}, {"commDestroy", CommDestroy}};
     for (auto& f : fns) {

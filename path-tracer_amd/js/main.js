@@ -3,7 +3,7 @@
 // (registerMesh x k -> instanceMesh x m -> await build() -> initPathTracer -> initDisplay -> loop { await step(); draw() }),
 // no browser.  The reference's demo meshes (cow / bunny / buddha) are not distributed with it, so the demo scene is
 // the floor it does bundle under a lattice of generated boxes standing in for the 100 instanced meshes (main.js:25-33).
-//   node main.js [--width W] [--height H] [--samples S] [--paths N] [--pools K] [--gpus G] [--grid G] [--out frame.png] [--progress K] [--json] [--ext]
+//   node main.js [--width W] [--height H] [--samples S] [--paths N] [--pools K] [--gpus G] [--grid G] [--out frame.png] [--progress K] [--json] [--ext] [--traversal reference|tolerance|auto]
 // --gpus G splits the samples over GPUs 0..G-1 (each builds the scene and renders its part of the pixel tickets with its own RNG
 // streams); the accumulation buffers are summed onto GPU 0 by one RCCL reduce before the final draw (pt-host.js initMultiGpu).
 // --progress K redraws (rewrites the PNG) every K steps, the headless form of the reference's draw-every-frame loop.
@@ -31,7 +31,7 @@ async function main() {
     const camera = { lookAt: [10, 10, 0], position: [15, 15, 5], fov: 60 }       // main.js:42-46
     const devices = [], scenes = [], tracers = []
     for (let g = 0; g < gpus; g++) {                 // one device, one scene replica and one tracer per GPU (G = 1: the reference's sequence)
-        const device = pt.requestDevice(+arg("device", 0) + g)
+        const device = pt.requestDevice(+arg("device", 0) + g, arg("traversal", "") ? { traversal: arg("traversal", "") } : {})
         const scene = pt.initScene(device)
         const box = scene.registerMesh({ file: BOX })
         const floor = scene.registerMesh({ file: FLOOR })

@@ -19,8 +19,16 @@ function addon() {
 }
 
 // ---- requestAdapter()/requestDevice() (main.js:3-4) ------------------------------------------------------------
-function requestDevice(deviceId = 0) {
+// options.traversal (no reference counterpart; pt_amd.h "tolerance mode"): "reference" (default, the bit-exact walk of scene.js:313-475),
+// "tolerance" (the 4-wide collapse north_star's allowance admits; the differing rays are counted in run()'s stats) or "auto" (tolerance
+// where the binary nodes exceed 256 MB); options.checkPeriod: one 64-ray queue block in N is walked a second time exactly (default 256).
+const TRAVERSAL = { reference: 0, tolerance: 1, auto: 2 }
+function requestDevice(deviceId = 0, options = {}) {
     const ctx = addon().create(deviceId)
+    if (options.traversal !== undefined || options.checkPeriod !== undefined) {
+        if (options.traversal !== undefined && !(options.traversal in TRAVERSAL)) throw new Error(`requestDevice: unknown traversal ${options.traversal}`)
+        addon().setTraversal(ctx, TRAVERSAL[options.traversal || "reference"], options.checkPeriod === undefined ? -1 : options.checkPeriod)
+    }
     return { ctx, destroy() { addon().destroy(ctx) } }
 }
 
@@ -189,7 +197,9 @@ function initPooledPathTracer(params) {
         const sum = f => rs.reduce((a, r) => a + r[f], 0)
         return { steps: Math.max(...rs.map(r => r.steps)), totalRays: sum("totalRays"), totalSamples: sum("totalSamples"),
                  stackOverflows: sum("stackOverflows"), extendMs: sum("extendMs"), extendLaunches: sum("extendLaunches"),
-                 traversalBytes: sum("traversalBytes"), wastedRays: sum("wastedRays"), pools: rs }
+                 traversalBytes: sum("traversalBytes"), wastedRays: sum("wastedRays"), checkedRays: sum("checkedRays"), mismatchedRays: sum("mismatchedRays"),
+                 flippedRays: sum("flippedRays"), beyondToleranceRays: sum("beyondToleranceRays"), lostHitRays: sum("lostHitRays"),
+                 maxRelDistDiff: Math.max(...rs.map(r => r.maxRelDistDiff)), pools: rs }
     }
     function readImage() { let img; for (let k = K - 1; k >= 0; k--) img = pools[k].readImage(); return img }   // each read adds that pool's open tickets
     async function step() {                                                       // every pool takes one step; the sizes add up
@@ -204,8 +214,9 @@ function initPooledPathTracer(params) {
 // ---- several GPUs of one node (SURVEY 8e; no reference counterpart) ---------------------------------------------------
 // The samples are split: GPU g of G gets the whole scene (build it once per device), the g-th part of the pixel tickets and
 // its own RNG streams -- shareOf(g, G, image, settings) gives the settings for its initPathTracer -- and renders into its own
-// accumulation buffer.  initMultiGpu(devices).reduceImage(root) then adds the buffers onto devices[root]'s with one RCCL
-// sum-reduce over xGMI (pt_comm_reduce_image); that image is the single-GPU image in form (sums of radiance and sample counts).
+// accumulation buffer.  initMultiGpu(devices).reduceImage(root) then MOVES the buffers onto devices[root]'s with one RCCL
+// sum-reduce over xGMI (pt_comm_reduce_image: the other GPUs' images are empty afterwards, so a later reduce counts nothing twice);
+// that image is the single-GPU image in form (sums of radiance and sample counts).
 function shareOf(g, G, image, settings) {
     const total = Math.ceil(image.width * image.height * settings.samples / 8)                   // logic.js:177
     const pools = settings.pools || 1, numPaths = settings.numPaths || 1000000

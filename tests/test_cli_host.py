@@ -99,3 +99,18 @@ def test_cli_render_equals_python_host_render(cli, pta, device, tmp_path, pools,
     np.testing.assert_allclose(rep["radianceSum"], img[..., 0].astype(np.float64).sum(), rtol=1e-6)
     disp = pta.init_display({"device": device, "image": {"buffer": pt.get_image_buffer(), "width": w, "height": h}})
     assert np.abs(read_png(str(out)).astype(np.int32) - disp.draw().astype(np.int32)).max() <= 1
+
+
+@pytest.mark.gpu
+def test_cli_tolerance_mode_option(cli, tmp_path):
+    """pt_cli --traversal tolerance / auto: the floor scene (two triangles) renders to the same counts as the reference walk -- the wide
+    walk of a two-triangle mesh has nothing to tie -- and an unknown mode is refused."""
+    reps = []
+    for mode in ("reference", "tolerance", "auto"):
+        r = subprocess.run([cli, "--width", "48", "--height", "32", "--samples", "8", "--paths", "2000", "--json", "--traversal", mode], capture_output=True, text=True, timeout=240)
+        assert r.returncode == 0, r.stdout + r.stderr
+        reps.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert all((x["steps"], x["rays"], x["sampleCount"]) == (reps[0]["steps"], reps[0]["rays"], 48 * 32 * 8) for x in reps)
+    assert all(abs(x["radianceSum"] - reps[0]["radianceSum"]) <= 1e-6 * reps[0]["radianceSum"] for x in reps)
+    r = subprocess.run([cli, "--traversal", "fastest"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2

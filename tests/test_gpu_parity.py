@@ -724,6 +724,21 @@ def test_rccl_reduce_at_world_size_one(pta, device, built):
         dev2.destroy()
 
 
+def test_reduce_semantics_at_world_size_two():
+    """pt_comm_reduce_image with TWO ranks (a second in-place sum of intact buffers would double-count): the reduce moves the
+    samples to the root and empties the other ranks, so a reduce in the middle of a render followed by one at its end gives exactly spp
+    samples per pixel and the oracle's sum of the two shares.  RCCL refuses two ranks on this box's one GPU, so the ranks are two contexts
+    of one process on the library's loopback backend (PT_COMM_LOOPBACK=1: the same pt_comm code path, the sum by a kernel instead of
+    ncclReduce); the backend is fixed per process, hence the child process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "loopback_reduce_check.py")], env=dict(os.environ, PT_COMM_LOOPBACK="1"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "loopback reduce ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 def test_pools_on_one_gpu(pta, orc, device, built):
     """settings.pools = 3: three path pools that borrow one scene and add into one image, driven together by
     pt_render_run_many.  Every pool traces exactly the rays of the oracle's run of the same share (its own slot base and

@@ -123,3 +123,40 @@ const BOX = ["v -0.5 -0.5 0", "v 0.5 -0.5 0", "v 0.5 0.5 0", "v -0.5 0.5 0", "v 
     # rays are built in f32 on both hosts; a pixel whose ray grazes an edge may resolve differently in the last bit
     assert abs(rep["sum"] - int((a * (1 + i % 7)).sum())) <= 255 * 7 * 4
     assert abs(rep["sum2"] - int((b * (1 + i % 5)).sum())) <= 255 * 5 * 4
+
+
+@needs_node
+@pytest.mark.gpu
+def test_node_tolerance_mode_and_check_stats():
+    """requestDevice(id, {traversal: "tolerance", checkPeriod: 1}) (pt_set_traversal_mode / pt_set_traversal_check through the addon):
+    run() reports every ray re-walked exactly, none beyond the tolerance, no reference hit lost; an unknown mode throws."""
+    code = """
+const pt = require('./pt-host.js')
+const BOX = ["v -0.5 -0.5 0", "v 0.5 -0.5 0", "v 0.5 0.5 0", "v -0.5 0.5 0", "v -0.5 -0.5 1.4", "v 0.5 -0.5 1.4", "v 0.5 0.5 1.4", "v -0.5 0.5 1.4",
+             "f 1 4 3 2", "f 5 6 7 8", "f 1 2 6 5", "f 3 4 8 7", "f 1 5 8 4", "f 2 3 7 6"].join("\\n")
+const FLOOR = "v -10.0 -10.0 0.0\\nv  10.0 -10.0 0.0\\nv  10.0  10.0 0.0\\nv -10.0  10.0 0.0\\n\\nf 1 2 3\\nf 1 3 4"
+;(async () => {
+  let threw = false
+  try { pt.requestDevice(0, {traversal: "fastest"}) } catch (e) { threw = true }
+  const out = {threw}
+  for (const traversal of ["reference", "tolerance"]) {
+    const device = pt.requestDevice(0, {traversal, checkPeriod: 1}), scene = pt.initScene(device)
+    const box = scene.registerMesh({file: BOX}), floor = scene.registerMesh({file: FLOOR})
+    for (let i = 0; i < 9; i++) scene.instanceMesh(box, [8 + (i % 3), 8 + Math.floor(i / 3), -1.3], [0, 0, 0.3 * i], [0.6, 0.6, 0.6], 1)
+    scene.instanceMesh(floor, [10, 10, -1.3], [0, 0, 0], [5, 5, 5], 0)
+    await scene.build()
+    const tracer = pt.initPathTracer({device, scene, image: {width: 64, height: 48}, camera: {position: [15, 15, 5], lookAt: [10, 10, 0], fov: 60}, settings: {samples: 16, numPaths: 3000}})
+    const rs = await tracer.run()
+    out[traversal] = {rays: rs.totalRays, samples: rs.totalSamples, checked: rs.checkedRays, mismatched: rs.mismatchedRays, beyond: rs.beyondToleranceRays, lost: rs.lostHitRays, rel: rs.maxRelDistDiff}
+    device.destroy()
+  }
+  console.log(JSON.stringify(out))
+})().catch(e => { console.error(e); process.exit(1) })
+"""
+    r = subprocess.run([NODE, "-e", code], cwd=JS, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rep["threw"] and rep["reference"]["checked"] == 0
+    t = rep["tolerance"]
+    assert t["samples"] == 64 * 48 * 16 and t["checked"] == t["rays"] > 0
+    assert t["mismatched"] <= 1e-3 * t["rays"] and t["beyond"] == 0 and t["lost"] == 0 and t["rel"] <= 1e-6
