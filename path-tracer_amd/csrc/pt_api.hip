@@ -390,7 +390,14 @@ int pt_create(int device_id, pt_ctx** out) {
     }
     c->own_stream = true;
     c->extend_variant = -1;  // automatic: variant 4 (kind-scheduled walk)
-    if (const char* v = getenv("PT_EXTEND_VARIANT")) c->extend_variant = atoi(v);
+    if (const char* v = getenv("PT_EXTEND_VARIANT")) {       // measurement override; anything but a variant number is refused, not guessed at
+        char* end = nullptr; long n = strtol(v, &end, 10);
+        if (end == v || *end != 0 || n < -1 || n >= ptk_extend_num_variants()) {
+            (void)hipStreamDestroy(c->stream); delete c;
+            return fail(nullptr, PT_ERR_ARG, std::string("pt_create: PT_EXTEND_VARIANT=") + v + " is not a variant (-1 .. " + std::to_string(ptk_extend_num_variants() - 1) + ")");
+        }
+        c->extend_variant = (int)n;
+    }
     *out = c;
     return PT_OK;
 }

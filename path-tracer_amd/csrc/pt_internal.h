@@ -176,10 +176,9 @@ int64_t ptk_extend_waves(int num_paths, int variant);   // waves the launch of t
 int ptk_extend_num_variants();
 const char* ptk_extend_variant_name(int v);
 // Extend over n caller rays (o / d: `stride` floats per ray, 4 = float4 records, 3 = packed).  Any output may be null.
-// spill: ptk_direct_spill_ints(n) ints.
+// spill: ptk_spill_ints(n) ints (sized for the smallest LDS share of any variant, so more than this kernel's 24-entry share needs).
 void ptk_extend_direct(const SceneView& sc, const float* o, const float* d, int stride, int n, int32_t* hit_obj,
                        int32_t* hit_tri, float* hit_dist, int4* counts4, int32_t* spill, StepHeader* hdr, hipStream_t s);
-size_t ptk_direct_spill_ints(int64_t n_rays);
 void ptk_camera_frame(const RenderConst& rc, CameraFrame* out_dev, hipStream_t s);   // one thread; the host copies the result into rc.frame
 void ptk_flush_tickets(const PathState& ps, int num_paths, float* image, hipStream_t s);
 void ptk_tonemap(const float4* image, int64_t n_pixels, uint32_t* rgba8, hipStream_t s);

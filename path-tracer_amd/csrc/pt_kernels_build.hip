@@ -123,6 +123,9 @@ __global__ __launch_bounds__(PT_BLOCK) void k_up_pass(const int32_t* __restrict_
         atomicExch(slot + 1, pack2(mn.z, __int_as_float(w_idx)));
         atomicExch(slot + 2, pack2(mx.x, mx.y));
         atomicExch((unsigned*)(slot + 3), __float_as_uint(mx.z));
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__GFX9__)
+#error "k_up_pass: the hand-over below waits for its atomics with vmcnt, which counts no-return atomics on gfx9-family targets only (gfx10+ count them in vscnt); build for a gfx9 target (gfx950) or use acq_rel atomics here"
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my slot is in memory before my arrival counts
         int arrived = atomicAdd((int*)nd + 7, 1);          // f_1 doubles as the arrival counter (:230)
         if (arrived == 0) return;                          // first arrival stops (:242)

@@ -197,8 +197,9 @@ __device__ __forceinline__ bool trav_step(const SceneView& sc, Ray& r, const STK
 // instructions, triangle 88 -> 112, one switch body of 182 for the two of 131 + 134), so on identical queues the launch issues MORE
 // vector instructions (+14 % on the 82 k-triangle mesh, +56 % on the one-object 10 M-triangle grid, whose walk is inner nodes and
 // triangles only) -- a model fed with the oracle's per-ray kind sequences had promised 1.4x fewer, by pricing the bodies too low.
-// What it does buy is fewer waits (SQ_WAIT_ANY -14 %): in the full render it is +3...8 % on scenes with several objects and -12 %
-// on the one-object grid, so the library picks it only for scenes with more than one object (pt_api.hip).
+// What it does buy is fewer waits (SQ_WAIT_ANY -14 %): in the full render it was +3...8 % on scenes with several objects and -12 %
+// on the one-object grid with the first weights; with the inner body's weight per scene (SceneView::sched_wi: 3 for one object, 6
+// otherwise) it wins there too, and variant 4 is the library's default for every scene (pt_api.hip extend_variant_of).
 // --------------------------------------------------------------------------------------------
 // (The tolerance-mode kernels need 65-72 registers, 7 waves per SIMD.  Capped at 64 for 8 waves they spill two registers inside the
 // outer loop and lose 11 %: profiles/r03_wide_occupancy_ab.txt.)
@@ -688,7 +689,6 @@ int64_t ptk_extend_waves(int num_paths, int variant) {
     int block = (variant == 0 || variant >= 3) ? 256 : 64;   // (variant 5 is always 256)   // variants 3 and 4 fall back to 64 when the scene does not fit: an upper bound then
     return (int64_t)((num_paths + block - 1) / block) * (block / 64);
 }
-size_t ptk_direct_spill_ints(int64_t n_rays) { return (size_t)pad_to(n_rays, 256) * (PT_STACK_SIZE - PT_LDS_STACK); }
 void ptk_extend_direct(const SceneView& sc, const float* o, const float* d, int stride, int n, int32_t* hit_obj, int32_t* hit_tri,
                        float* hit_dist, int4* counts4, int32_t* spill, StepHeader* hdr, hipStream_t s) {
     const dim3 grid((unsigned)((n + PT_BLOCK - 1) / PT_BLOCK)), block(PT_BLOCK);
