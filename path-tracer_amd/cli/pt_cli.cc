@@ -101,7 +101,7 @@ static int dump_host(const std::string& file, const std::string& trs) {
 
 int main(int argc, char** argv) {
     std::vector<std::string> objs, insts; std::string cam, out; bool json = false;
-    int width = 512, height = 512, samples = 16, paths = 0, device = 0, progress = 0, pools = 1, gpus = 1;
+    int width = 512, height = 512, samples = 16, paths = 0, device = 0, progress = 0, pools = 0, gpus = 1;
     pt_render_ext ext; memset(&ext, 0, sizeof ext); bool have_ext = false; int traversal = PT_TRAVERSAL_REFERENCE;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -137,6 +137,10 @@ int main(int argc, char** argv) {
         else if (a == "--json") json = true;
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
+    // neither --paths nor --pools: the measured-best shape for the frame (three pools of a quarter of its pixels each, 750,000 .. 2,000,000
+    // slots); the reference's own shape is --paths 1000000 --pools 1 (path-tracer.js:4), 38 % slower on MI355X
+    if (paths <= 0 && pools <= 0) { pools = 3; paths = (int)std::min<long long>(2000000, std::max<long long>(750000, (long long)width * height / 4)); }
+    pools = std::max(1, pools);
     std::vector<std::string> texts;
     if (objs.empty()) { texts.push_back(FLOOR_OBJ); if (insts.empty()) insts.push_back("0,10,10,-1.3,0,0,0,5,5,5,0"); }   // main.js:33
     for (const std::string& f : objs) { std::string t; if (!read_file(f, t)) { fprintf(stderr, "cannot read %s\n", f.c_str()); return 2; } texts.push_back(t); }

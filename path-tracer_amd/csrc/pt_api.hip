@@ -73,6 +73,7 @@ struct pt_ctx {
     float4 *d_blas_nodes = nullptr, *d_blas_tris = nullptr, *d_tlas_nodes = nullptr, *d_objects = nullptr;
     float4* d_tri_records = nullptr;                    // SceneView::tris (edges + normal per packed triangle); d_blas_tris stays the reference's buffer
     float4* d_objects_top = nullptr; int32_t top_nodes = 0;   // tree-top blocks at node ids n_tris .. of d_blas_trav (SceneView::objects_top)
+    float4* d_soa = nullptr;                            // extend variant 7 only: d_blas_trav's BLAS and TLAS records as four arrays of quads (built on demand)
     float4* d_blas_trav = nullptr;                      // SceneView::blas: the packed BLAS with inner nodes in depth-first order; d_blas_nodes stays the reference's
     int32_t* d_tlas_perm = nullptr;
     // render
@@ -178,6 +179,7 @@ bool wide_in_use(const pt_ctx* c) { return c->d_wide && wide_wanted(c); }
 SceneView scene_view(const pt_ctx* c) {
     SceneView v; v.nodes = c->d_blas_trav; v.objects = c->d_objects; v.tris = c->d_tri_records;
     v.wide = wide_in_use(c) ? c->d_wide : nullptr; v.objects_wide = v.wide ? c->d_objects_wide : nullptr;
+    v.soa = c->d_soa; v.soa_stride = (int32_t)std::min<int64_t>(c->n_tris + c->n_objects, INT32_MAX);
     v.ext_mats = c->d_ext_mats; v.n_ext_mats = c->n_ext_mats; v.stack_bound = c->stack_bound;
     v.n_objects = c->n_objects; v.n_tris = (int32_t)std::min<int64_t>(c->n_tris, INT32_MAX);
     v.tlas_root = v.n_tris;
@@ -242,12 +244,13 @@ int build_mesh(pt_ctx* c, Mesh& m) {
 
 void free_scene(pt_ctx* c) {
     if (c->scene_borrowed) {
-        c->d_wide = c->d_objects_wide = nullptr; c->n_wide = 0;
+        c->d_wide = c->d_objects_wide = nullptr; c->n_wide = 0; c->d_soa = nullptr;
         c->d_blas_nodes = c->d_blas_tris = c->d_tlas_nodes = c->d_objects = c->d_tri_records = c->d_blas_trav = nullptr; c->d_tlas_perm = nullptr; c->scene_built = false;
         c->d_objects_top = nullptr; c->top_nodes = 0;
         return;
     }
     dfree(c->d_wide); dfree(c->d_objects_wide); c->d_wide = c->d_objects_wide = nullptr; c->n_wide = 0;
+    dfree(c->d_soa); c->d_soa = nullptr;
     dfree(c->d_blas_nodes); dfree(c->d_blas_tris); dfree(c->d_tlas_nodes); dfree(c->d_objects); dfree(c->d_tlas_perm); dfree(c->d_tri_records); dfree(c->d_blas_trav);
     dfree(c->d_objects_top); c->d_objects_top = nullptr; c->top_nodes = 0;
     c->d_blas_nodes = c->d_blas_tris = c->d_tlas_nodes = c->d_objects = c->d_tri_records = c->d_blas_trav = nullptr; c->d_tlas_perm = nullptr; c->scene_built = false;
@@ -334,6 +337,17 @@ int build_wide(pt_ctx* c) {
     return PT_OK;
 }
 
+// extend variant 7: the structure-of-arrays copy of the walk's nodes, made when first asked for
+int ensure_soa(pt_ctx* c) {
+    if (c->d_soa || !c->scene_built || c->scene_borrowed) return PT_OK;
+    const int64_t n = c->n_tris + c->n_objects; int rc;
+    if ((rc = dalloc(c, &c->d_soa, (size_t)n * 4, false))) return rc;
+    ptk_soa_split(c->d_blas_trav, n, c->d_soa, c->stream);
+    HIPOK(c, hipGetLastError());
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
 // what the host learns from a header it has read back
 void note_header(pt_ctx* c, const StepHeader& h) {
     c->known_rays = h.n_rays;
@@ -411,7 +425,7 @@ int pt_create_sharing_scene(pt_ctx* src, pt_ctx** out) {
     c->scene_borrowed = true; c->scene_built = true; c->extend_variant = src->extend_variant;
     c->n_tris = src->n_tris; c->n_objects = src->n_objects; c->n_meshes_used = src->n_meshes_used; c->stack_bound = src->stack_bound;
     c->d_blas_nodes = src->d_blas_nodes; c->d_blas_tris = src->d_blas_tris; c->d_tlas_nodes = src->d_tlas_nodes; c->d_objects = src->d_objects;
-    c->d_tlas_perm = src->d_tlas_perm; c->d_tri_records = src->d_tri_records; c->d_blas_trav = src->d_blas_trav; c->d_objects_top = src->d_objects_top; c->top_nodes = src->top_nodes; c->d_wide = src->d_wide; c->d_objects_wide = src->d_objects_wide; c->n_wide = src->n_wide; c->traversal_mode = src->traversal_mode; c->check_period = src->check_period;
+    c->d_tlas_perm = src->d_tlas_perm; c->d_tri_records = src->d_tri_records; c->d_blas_trav = src->d_blas_trav; c->d_soa = src->d_soa; c->d_objects_top = src->d_objects_top; c->top_nodes = src->top_nodes; c->d_wide = src->d_wide; c->d_objects_wide = src->d_objects_wide; c->n_wide = src->n_wide; c->traversal_mode = src->traversal_mode; c->check_period = src->check_period;
     c->lender = src; src->borrowers.push_back(c);
     return PT_OK;
 }
@@ -560,6 +574,7 @@ int pt_scene_build(pt_ctx* c, const pt_instance* inst, int n_inst) {
     HIPOK(c, hipGetLastError());
     HIPOK(c, hipStreamSynchronize(c->stream));
     c->scene_built = true;
+    if (c->extend_variant == 7 && (rc = ensure_soa(c))) return rc;
     if ((rc = scene_stack_bound(c))) return rc;
     return wide_wanted(c) ? build_wide(c) : PT_OK;
 }
@@ -991,6 +1006,7 @@ int pt_extend_variants(pt_ctx* c, int variant, char* name_out, size_t name_cap) 
 int pt_set_extend_variant(pt_ctx* c, int variant) {
     if (!c || variant < -1 || variant >= ptk_extend_num_variants()) return fail(c, PT_ERR_ARG, "pt_set_extend_variant: no such variant");
     c->extend_variant = variant;
+    if (variant == 7) { HIPOK(c, hipSetDevice(c->device)); return ensure_soa(c); }
     return PT_OK;
 }
 
@@ -998,6 +1014,7 @@ int pt_extend_replay(pt_ctx* c, int variant, int reps, double* avg_us) {
     if (!c || !avg_us || reps < 1 || variant < 0 || variant >= ptk_extend_num_variants()) return fail(c, PT_ERR_ARG, "pt_extend_replay: bad argument");
     if (!c->render_ready || c->step == 0) return fail(c, PT_ERR_STATE, "pt_extend_replay: take at least one step first");
     HIPOK(c, hipSetDevice(c->device));
+    if (variant == 7) { int r7 = ensure_soa(c); if (r7) return r7; }
     hipEvent_t e0, e1; HIPOK(c, hipEventCreate(&e0)); HIPOK(c, hipEventCreate(&e1));
     SceneView sv = scene_view(c);
     double total_ms = 0;

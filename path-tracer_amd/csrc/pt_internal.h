@@ -26,6 +26,8 @@ struct SceneView {
                              //   ids [n_tris, n_tris + n_objects)     the TLAS, its inner links moved up by n_tris (k_tlas_rebase): a walk
                              //                                        starts at tlas_root and never asks which tree a node id belongs to
                              //   ids [top_base, top_base + top_nodes) tree-top blocks (below)
+    const float4* soa;       // extend variant 7 only (A/B of a structure-of-arrays node layout), else null: quad k of node i of `nodes` at soa[k * soa_stride + i]
+    int32_t soa_stride;      // = n_tris + n_objects
     const float4* objects;   // pt_object[n_objects]
     const float4* tris;      // per triangle {v0, nx}{v1 - v0, ny}{v2 - v0, nz}: the reference's pt_triangle with what every ray
                              // would recompute from it -- the two edges (scene.js:479-481) and the unit normal
@@ -126,6 +128,7 @@ void ptk_dfs_index(const int32_t* parents, const int32_t* first, int64_t n, int3
 void ptk_top_block(const float4* packed_nodes, const int32_t* dfs, const int32_t* top_nodes, int64_t offset, int64_t n, int levels, int top_id, float4* trav_nodes, hipStream_t s);
 void ptk_tlas_rebase(const float4* tlas_nodes, int n, int delta, float4* out /* the TLAS part of SceneView::nodes */, hipStream_t s);
 void ptk_objects_top(const float4* objects, int n, const int32_t* mesh_root, const int32_t* top_root, int n_meshes, float4* out, hipStream_t s);
+void ptk_soa_split(const float4* nodes, int64_t n, float4* soa /* 4 x n quads */, hipStream_t s);
 void ptk_reorder_nodes(const float4* packed_nodes, const int32_t* dfs, int64_t offset, int64_t n, float4* trav_nodes, hipStream_t s);
 void ptk_up_pass(const int32_t* idx, const float4* aabb, const int32_t* parents, int64_t n, float4* nodes /* zeroed */, hipStream_t s);
 void ptk_rearrange(const float4* tris_in, const int32_t* idx, int64_t n, float4* tris_out, hipStream_t s);

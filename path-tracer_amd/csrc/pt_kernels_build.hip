@@ -286,6 +286,13 @@ __global__ __launch_bounds__(PT_BLOCK) void k_reorder_nodes(const float4* __rest
     float4* dst = trav + 4 * (offset + dfs[i]);
     dst[0] = q0; dst[1] = q1; dst[2] = q2; dst[3] = q3;
 }
+// extend variant 7 (A/B): the walk's node array as four arrays of quads
+__global__ __launch_bounds__(PT_BLOCK) void k_soa_split(const float4* __restrict__ nodes, int64_t n, float4* __restrict__ soa) {
+    int64_t i = (int64_t)blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    for (int k = 0; k < 4; k++) soa[k * n + i] = nodes[4 * i + k];
+}
+void ptk_soa_split(const float4* nodes, int64_t n, float4* soa, hipStream_t s) { hipLaunchKernelGGL(k_soa_split, grid_for(n), dim3(PT_BLOCK), 0, s, nodes, n, soa); }
 void ptk_dfs_index(const int32_t* parents, const int32_t* first, int64_t n, int32_t* dfs, int32_t* top_nodes, uint8_t* depth, hipStream_t s) {
     hipLaunchKernelGGL(k_dfs_index, grid_for(n), dim3(PT_BLOCK), 0, s, parents, first, (int)n, dfs, top_nodes, depth);
 }

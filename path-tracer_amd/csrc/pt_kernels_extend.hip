@@ -225,17 +225,22 @@ __device__ __forceinline__ bool trip_guard(Ray& r) {
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef const volatile __attribute__((address_space(3))) v4f* LdsQuads;   // typed as LDS, and volatile, so that the two fetch paths below stay two
                                                                           // (the compiler otherwise merges them into flat loads through a select of addresses)
-template <bool COUNT, class STK, bool TOP = false, bool WIDE = false>
+// TOP == 2 (extend variant 7, an A/B of north_star's "structure-of-arrays node buffers"): the four quads of a node come from four arrays
+// (SceneView::soa: quad k of node i at soa[k * soa_stride + i]) instead of one 64-B record.
+template <bool COUNT, class STK, int TOP = 0, bool WIDE = false>
 __device__ __forceinline__ int op_inner(const SceneView& sc, Ray& r, const STK& stk, LdsQuads lds = nullptr) {      // :392-439
     // One exit: a lane stopped by a guard runs the visit like the others (it changes no hit; its stack slot and node are its own and
     // never read again) and is retired at the end.  Early returns here cost every lane of every pass a dozen register copies.
     r.iter++;
     const bool stop = !STK::shallow && r.iter > PT_MAX_ITERS;
     float4 q0, q1, q2, q3;
-    if (TOP && r.node >= sc.n_tris) {
+    if (TOP == 1 && r.node >= sc.n_tris) {
         LdsQuads nd = lds + 4 * (r.node - sc.n_tris);
         const v4f a = nd[0], b = nd[1], c = nd[2], d = nd[3];
         q0 = make_float4(a.x, a.y, a.z, a.w); q1 = make_float4(b.x, b.y, b.z, b.w); q2 = make_float4(c.x, c.y, c.z, c.w); q3 = make_float4(d.x, d.y, d.z, d.w);
+    } else if (TOP == 2) {
+        const float4* nd = rec32<1>(sc.soa, r.node);
+        q0 = nd[0]; q1 = nd[sc.soa_stride]; q2 = nd[2 * (int64_t)sc.soa_stride]; q3 = nd[3 * (int64_t)sc.soa_stride];
     } else {
         const float4* nd = rec32<4>(sc.nodes, r.node);
         q0 = nd[0]; q1 = nd[1]; q2 = nd[2]; q3 = nd[3];
@@ -340,7 +345,7 @@ __device__ __forceinline__ int op_switch(const SceneView& sc, Ray& r) {
     return kind_after<WIDE>(r);
 }
 // Runs the walk of every lane of the wave to its end.  `kind`: PT_K_INNER for a lane with a ray, PT_K_DONE for one without.
-template <bool COUNT, class STK, bool TOP = false>
+template <bool COUNT, class STK, int TOP = 0>
 __device__ __forceinline__ void traverse_scheduled(const SceneView& sc, Ray& r, const STK& stk, int kind, LdsQuads lds = nullptr, StepHeader* hdr = nullptr) {
     int np_i = 0, np_l = 0, np_s = 0;      // COUNT: passes by body (measurement: lane use = lane visits / (64 x passes))
     // Same sequence of passes as "count, choose, run one body" in one loop; written as a tight loop per body inside the outer loop so
@@ -450,7 +455,7 @@ __device__ __forceinline__ void publish(unsigned long long ov, unsigned long lon
 // (rc.chk_buf, two halves by step parity), and the NEXT step's launch starts with rc.chk_cap extra workgroups that take those rays,
 // walk them exactly and compare: they are dispatched first, last as long as an ordinary wave, and share nothing with the other
 // workgroups but the counters.  (pt_render_run always issues at least one step after the last one that traced a ray.)
-template <int LDS_N, int BLOCK, bool COUNT, int ORDER, bool LOG, bool LOGIC, bool WIDE = false, int SCENE_QUADS = 0, bool SHALLOW = false, bool SCHED = false, bool TOP = false, bool CHECK = false>
+template <int LDS_N, int BLOCK, bool COUNT, int ORDER, bool LOG, bool LOGIC, bool WIDE = false, int SCENE_QUADS = 0, bool SHALLOW = false, bool SCHED = false, int TOP = 0, bool CHECK = false>
 __global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView sc, StepHeader* hdr, const int32_t* __restrict__ cam_q,
                                                         const int32_t* __restrict__ mat_q, int32_t* spill, int64_t spill_stride,
                                                         unsigned long long* wave_log, float* __restrict__ image, uint8_t* __restrict__ code_out,
@@ -506,7 +511,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView 
     // take lets another one start in the wave slots that the finished waves of resident workgroups have already left.
     // (Sizing the stack part to the scene's stack bound as well was measured: the run-time LDS base costs more than it returns.)
     extern __shared__ float4 s_scene[];
-    if (TOP) {                                                   // [nodes from id n_tris on: tlas, top blocks | objects (with top roots)]
+    if (TOP == 1) {                                              // [nodes from id n_tris on: tlas, top blocks | objects (with top roots)]
         const int t4 = 4 * (sc.n_objects + sc.top_nodes), total = t4 + 8 * sc.n_objects;
         const float4* high = sc.nodes + 4 * (int64_t)sc.n_tris;
         for (int i = threadIdx.x; i < total; i += BLOCK) s_scene[i] = i < t4 ? high[i] : sc.objects[i - t4];
@@ -619,7 +624,7 @@ static int64_t pad_to(int64_t n, int64_t m) { return (n + m - 1) / m * m; }
 // The spill is sized for the smallest LDS share any variant uses (12 entries) and the largest slot count.
 size_t ptk_spill_ints(int64_t n_rays) { return (size_t)pad_to(n_rays, 256) * (PT_STACK_SIZE - PT_STAGED_LDS_STACK); }
 
-template <int LDS_N, int BLOCK, int ORDER, bool WIDE = false, int SCENE_QUADS = 0, bool SHALLOW = false, bool SCHED = false, bool TOP = false, bool CHECK = false>
+template <int LDS_N, int BLOCK, int ORDER, bool WIDE = false, int SCENE_QUADS = 0, bool SHALLOW = false, bool SCHED = false, int TOP = 0, bool CHECK = false>
 static void launch_queue(const PathState& ps, int num_paths, int grid_rays, SceneView sc, StepHeader* hdr, const int32_t* cam_q,
                          const int32_t* mat_q, int32_t* spill, int count, unsigned long long* wave_log, float* image, uint8_t* code,
                          unsigned long long* rec_next, const RenderConst& rc, hipStream_t s) {
@@ -627,8 +632,8 @@ static void launch_queue(const PathState& ps, int num_paths, int grid_rays, Scen
     // grid_rays: an upper bound of this step's queue length the host knows (the pool size until the tickets have run out; then
     // the last queue length it has seen: once no ticket is left, a step's rays are a subset of the step before's)
     dim3 grid((unsigned)((std::max(1, std::min(num_paths, grid_rays)) + BLOCK - 1) / BLOCK));
-    const size_t scene_lds = TOP ? 16 * (size_t)(12 * sc.n_objects + 4 * sc.top_nodes) : SCENE_QUADS > 0 ? 16 * (size_t)(12 * sc.n_objects + 7 * sc.n_tris) : 0;
-    if (TOP) sc.objects = sc.objects_top;
+    const size_t scene_lds = TOP == 1 ? 16 * (size_t)(12 * sc.n_objects + 4 * sc.top_nodes) : SCENE_QUADS > 0 ? 16 * (size_t)(12 * sc.n_objects + 7 * sc.n_tris) : 0;
+    if (TOP == 1) sc.objects = sc.objects_top;
 #define PT_LAUNCH(COUNT, LOG, LOGIC) hipLaunchKernelGGL((k_extend_queue<LDS_N, BLOCK, COUNT, ORDER, LOG, LOGIC, WIDE, SCENE_QUADS, SHALLOW, SCHED, TOP, CHECK && LOGIC && !(COUNT)>), \
                                                        dim3(grid.x + ((CHECK && LOGIC && !(COUNT)) ? (unsigned)rc.chk_cap : 0u)), dim3(BLOCK), scene_lds, s, ps, sc, hdr, \
                                                        cam_q, mat_q, spill, stride, wave_log, image, code, rec_next, rc)
@@ -657,16 +662,17 @@ static const char* kVariantNames[] = {"256-thread workgroups, 24 LDS stack entri
                                       "as 2; a scene of <= 8 KB is staged in LDS (256-thread workgroups, 12 LDS stack entries)",
                                       "as 3, kind-scheduled: each pass of the loop the wave runs the one body (inner node, triangle, object switch) that advances most lanes",
                                       "as 4 with 256-thread workgroups and 12 LDS stack entries whatever the scene's size (the workgroup shape an LDS-staged tree top needs)",
-                                      "as 5; the TLAS, the objects and the first levels of every mesh's tree are staged in LDS (scenes too large to stage whole)"};
-int ptk_extend_num_variants() { return 7; }
-const char* ptk_extend_variant_name(int v) { return (v >= 0 && v < 7) ? kVariantNames[v] : "?"; }
+                                      "as 5; the TLAS, the objects and the first levels of every mesh's tree are staged in LDS (scenes too large to stage whole)",
+                                      "as 4 with the walk's node records split into four arrays of quads (structure of arrays)"};
+int ptk_extend_num_variants() { return 8; }
+const char* ptk_extend_variant_name(int v) { return (v >= 0 && v < 8) ? kVariantNames[v] : "?"; }
 void ptk_extend_queue(const PathState& ps, const RenderConst& rc, const SceneView& sc, StepHeader* hdr, const int32_t* cam_q,
                       const int32_t* mat_q, int32_t* spill, int count, int variant, unsigned long long* wave_log, float* image, uint8_t* code,
                       unsigned long long* rec_next, int grid_rays, hipStream_t s) {
     if (sc.wide && variant == 2)                                                                                                                                         // tolerance mode, per-lane loop (A/B)
         launch_queue<16, 64, 2, true>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
     else if (sc.wide && rc.check_period > 0)                                                                                                                             // tolerance mode, kind-scheduled, sampled exact re-walk
-        launch_queue<16, 64, 2, true, 0, false, true, false, true>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
+        launch_queue<16, 64, 2, true, 0, false, true, 0, true>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
     else if (sc.wide)      launch_queue<16, 64, 2, true, 0, false, true>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
     else if (variant == 0) launch_queue<24, 256, 1>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
     else if (variant == 1) launch_queue<16, 64, 1>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
@@ -680,13 +686,16 @@ void ptk_extend_queue(const PathState& ps, const RenderConst& rc, const SceneVie
         }
     }
     else if (variant == 6 && sc.top_nodes > 0 && sc.objects_top && 12 * (int64_t)sc.n_objects + 4 * (int64_t)sc.top_nodes <= PT_SCENE_LDS_QUADS)
-        launch_queue<PT_STAGED_LDS_STACK, 256, 2, false, PT_SCENE_LDS_QUADS, false, true, true>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
+        launch_queue<PT_STAGED_LDS_STACK, 256, 2, false, PT_SCENE_LDS_QUADS, false, true, 1>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
+    else if (variant == 7 && sc.soa)                                                                      // as 4, the node quads from four arrays
+        launch_queue<16, 64, 2, false, 0, false, true, 2>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
+    else if (variant == 7) launch_queue<16, 64, 2, false, 0, false, true>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
     else if (variant >= 5) launch_queue<PT_STAGED_LDS_STACK, 256, 2, false, 0, false, true>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
     else if (variant == 4) launch_queue<16, 64, 2, false, 0, false, true>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
     else                   launch_queue<16, 64, 2>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
 }
 int64_t ptk_extend_waves(int num_paths, int variant) {
-    int block = (variant == 0 || variant >= 3) ? 256 : 64;   // (variant 5 is always 256)   // variants 3 and 4 fall back to 64 when the scene does not fit: an upper bound then
+    int block = (variant == 0 || (variant >= 3 && variant != 7)) ? 256 : 64;   // (variant 5 is always 256)   // variants 3 and 4 fall back to 64 when the scene does not fit: an upper bound then
     return (int64_t)((num_paths + block - 1) / block) * (block / 64);
 }
 void ptk_extend_direct(const SceneView& sc, const float* o, const float* d, int stride, int n, int32_t* hit_obj, int32_t* hit_tri,

@@ -461,6 +461,13 @@ def default_pool_shape(width, height):
 
 
 def init_path_tracer(params):
+    """initPathTracer (path-tracer.js:1).  A caller that fixes neither settings.numPaths nor settings.pools gets default_pool_shape for
+    the frame (the reference's own shape -- one pool of NUM_PATHS = 1,000,000, path-tracer.js:4 -- costs 38 % of the throughput on
+    MI355X: bench.py `reference_pool_shape`); {"numPaths": 1000000, "pools": 1} asks for the reference's."""
+    s = params["settings"]
+    if "numPaths" not in s and "pools" not in s:
+        pools, paths = default_pool_shape(int(params["image"]["width"]), int(params["image"]["height"]))
+        params = dict(params, settings=dict(s, numPaths=paths, pools=pools))
     if int(params["settings"].get("pools", 1)) > 1:
         return PooledPathTracer(params)
     return PathTracer(params)

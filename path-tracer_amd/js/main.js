@@ -27,7 +27,8 @@ function arg(name, dflt) {
 async function main() {
     const width = +arg("width", 512), height = +arg("height", 512), samples = +arg("samples", 16), grid = +arg("grid", 10)
     const gpus = Math.max(1, +arg("gpus", 1)), t0 = Date.now()
-    const settings = Object.assign({ samples, numPaths: +arg("paths", 0), pools: +arg("pools", 1) }, arg("ext", false) ? EXT : {})
+    const shape = (arg("paths", "") === "" && arg("pools", "") === "") ? pt.defaultPoolShape(width, height) : { numPaths: +arg("paths", 0), pools: +arg("pools", 1) }
+    const settings = Object.assign({ samples }, shape, arg("ext", false) ? EXT : {})
     const camera = { lookAt: [10, 10, 0], position: [15, 15, 5], fov: 60 }       // main.js:42-46
     const devices = [], scenes = [], tracers = []
     for (let g = 0; g < gpus; g++) {                 // one device, one scene replica and one tracer per GPU (G = 1: the reference's sequence)
