@@ -140,9 +140,9 @@ void ptk_pack_mesh(const float4* src_nodes, const float4* src_tris, int64_t n, i
 // wide BVH): the traversal is bound by the number of dependent fetches and of 16-B lane requests it sends to L1, and this node is 4 quads
 // for four children instead of 4 quads for two.  Wide nodes are numbered in depth-first order of the wide tree, the meshes one after the
 // other (ptk_wide_count gives a mesh's count; only the binary nodes at even depths have one, a third of the triangle count).
-//   quad 0: frame origin x, y, z (f32) | biased exponents of the three power-of-two steps, one byte each
+//   quad 0: frame origin x, y, z (f32) | step.x (f32; the three steps are powers of two)
 //   quad 1: child ref[4] (>= 0 wide node, < 0 triangle leaf, PT_WIDE_EMPTY = unused slot)
-//   quad 2: lo.x[4] | lo.y[4] | lo.z[4] | hi.x[4]   (one byte per child)        quad 3: hi.y[4] | hi.z[4] | 0 | 0
+//   quad 2: lo.x[4] | lo.y[4] | lo.z[4] | hi.x[4]   (one byte per child)        quad 3: hi.y[4] | hi.z[4] | step.y | step.z
 // child box = origin + q * step.
 #define PT_WIDE_EMPTY 0x7fffffff
 #define PT_WIDE_QUADS 4

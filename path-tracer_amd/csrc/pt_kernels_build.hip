@@ -435,10 +435,11 @@ __global__ __launch_bounds__(PT_BLOCK) void k_collapse_wide(const float4* __rest
         }
     }
     float4* w = wide + PT_WIDE_QUADS * (int64_t)(wide_base + rank[dfs[i]]);
-    w[0] = make_float4(org[0], org[1], org[2], __uint_as_float(ebits));
+    (void)ebits;                                    // the steps are powers of two; they are stored as floats (the record has the room, a visit saves the decode)
+    w[0] = make_float4(org[0], org[1], org[2], step[0]);
     w[1] = make_float4(__int_as_float(ref[0]), __int_as_float(ref[1]), __int_as_float(ref[2]), __int_as_float(ref[3]));
     w[2] = make_float4(__uint_as_float(qlo[0]), __uint_as_float(qlo[1]), __uint_as_float(qlo[2]), __uint_as_float(qhi[0]));
-    w[3] = make_float4(__uint_as_float(qhi[1]), __uint_as_float(qhi[2]), 0.0f, 0.0f);
+    w[3] = make_float4(__uint_as_float(qhi[1]), __uint_as_float(qhi[2]), step[1], step[2]);
 }
 void ptk_collapse_wide(const float4* blas_nodes, int64_t offset, int64_t n, const int32_t* dfs, const uint8_t* depth, const int32_t* rank,
                        int32_t wide_base, float4* wide, hipStream_t s) {

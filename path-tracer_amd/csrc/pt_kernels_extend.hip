@@ -137,8 +137,7 @@ __device__ __forceinline__ bool trav_step(const SceneView& sc, Ray& r, const STK
         const float4* nd = sc.wide + PT_WIDE_QUADS * (int64_t)r.node;
         float4 h = nd[0], rf = nd[1], qa = nd[2], qb = nd[3];
         if (COUNT) r.n_inner++;                                 // one 64-B record
-        unsigned eb = __float_as_uint(h.w);
-        f3 org = F3(h), st = F3(__uint_as_float((eb & 0xffu) << 23), __uint_as_float(((eb >> 8) & 0xffu) << 23), __uint_as_float(((eb >> 16) & 0xffu) << 23));
+        f3 org = F3(h), st = F3(h.w, qb.z, qb.w);
         unsigned lx = __float_as_uint(qa.x), ly = __float_as_uint(qa.y), lz = __float_as_uint(qa.z), hx = __float_as_uint(qa.w),
                  hy = __float_as_uint(qb.x), hz = __float_as_uint(qb.y);
         int r0 = __float_as_int(rf.x), r1 = __float_as_int(rf.y), r2 = __float_as_int(rf.z), r3 = __float_as_int(rf.w);
@@ -286,9 +285,7 @@ __device__ __forceinline__ int op_wide(const SceneView& sc, Ray& r, const STK& s
     const float4* nd = rec32<PT_WIDE_QUADS>(sc.wide, r.node);
     const float4 h = nd[0], rf = nd[1], qa = nd[2], qb = nd[3];
     if (COUNT) r.n_inner += stop ? 0 : 1;                       // one 64-B record
-    const unsigned eb = __float_as_uint(h.w);
-    const f3 st = F3(__uint_as_float((eb & 0xffu) << 23), __uint_as_float(((eb >> 8) & 0xffu) << 23), __uint_as_float(((eb >> 16) & 0xffu) << 23));
-    const f3 a = st * r.id, b = (F3(h) - r.o) * r.id;
+    const f3 a = F3(h.w, qb.z, qb.w) * r.id, b = (F3(h) - r.o) * r.id;
     const unsigned lx = __float_as_uint(qa.x), ly = __float_as_uint(qa.y), lz = __float_as_uint(qa.z), hx = __float_as_uint(qa.w),
                    hy = __float_as_uint(qb.x), hz = __float_as_uint(qb.y);
     const bool bx = r.id.x < 0.0f, by = r.id.y < 0.0f, bz = r.id.z < 0.0f;
@@ -305,15 +302,24 @@ __device__ __forceinline__ int op_wide(const SceneView& sc, Ray& r, const STK& s
     float k0 = PT_CHILD_T(0, r0), k1 = PT_CHILD_T(1, r1), k2 = PT_CHILD_T(2, r2), k3 = PT_CHILD_T(3, r3);
 #undef PT_CHILD_T
     near_first(k0, r0, k1, r1); near_first(k2, r2, k3, r3); near_first(k0, r0, k2, r2); near_first(k1, r1, k3, r3); near_first(k1, r1, k2, r2);
-    const int nv = (k0 != INF) + (k1 != INF) + (k2 != INF) + (k3 != INF);
-    const bool full = !STK::shallow && r.sp + nv - 1 > PT_STACK_SIZE;        // pushes onto a full stack end the ray
-    if (!full) {
-        if (nv > 3) { stk.put(r.sp, r3); r.sp += 1; }
-        if (nv > 2) { stk.put(r.sp, r2); r.sp += 1; }
-        if (nv > 1) { stk.put(r.sp, r1); r.sp += 1; }
+    // sorted: the valid children come first, so child j is valid iff its key is finite; children 1..3 are pushed farthest first, i.e.
+    // child j lands j entries below the new top of the stack
+    const bool p1 = k1 != INF, p2 = k2 != INF, p3 = k3 != INF;
+    const int top = r.sp + (int)p1 + (int)p2 + (int)p3;
+    const bool full = !STK::shallow && top > PT_STACK_SIZE;                 // pushes onto a full stack end the ray
+    if (STK::shallow || !__any(top > STK::lds_n)) {                         // ONE wave-uniform test for the three pushes: all of them stay in LDS
+        int* t = stk.lds + top * STK::block;
+        if (p1) t[-1 * STK::block] = r1;
+        if (p2) t[-2 * STK::block] = r2;
+        if (p3) t[-3 * STK::block] = r3;
+    } else if (!full) {
+        if (p1) stk.put(top - 1, r1);
+        if (p2) stk.put(top - 2, r2);
+        if (p3) stk.put(top - 3, r3);
     }
+    r.sp = full ? r.sp : top;
     r.node = r0;
-    if (nv == 0) { r.sp -= 1; r.node = stk.get(r.sp); }
+    if (k0 == INF) { r.sp -= 1; r.node = stk.get(r.sp); }
     if (!STK::shallow) r.overflow |= (stop || full) ? 1 : 0;
     return (stop || full) ? PT_K_DONE : kind_after<true>(r);
 }
