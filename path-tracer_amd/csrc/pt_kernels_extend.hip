@@ -462,7 +462,7 @@ __device__ __forceinline__ void publish(unsigned long long ov, unsigned long lon
 // walk them exactly and compare: they are dispatched first, last as long as an ordinary wave, and share nothing with the other
 // workgroups but the counters.  (pt_render_run always issues at least one step after the last one that traced a ray.)
 template <int LDS_N, int BLOCK, bool COUNT, int ORDER, bool LOG, bool LOGIC, bool WIDE = false, int SCENE_QUADS = 0, bool SHALLOW = false, bool SCHED = false, int TOP = 0, bool CHECK = false>
-__global__ __launch_bounds__(BLOCK) void k_extend_queue(PathState ps, SceneView sc, StepHeader* hdr, const int32_t* __restrict__ cam_q,
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96))) void k_extend_queue(PathState ps, SceneView sc, StepHeader* hdr, const int32_t* __restrict__ cam_q,
                                                         const int32_t* __restrict__ mat_q, int32_t* spill, int64_t spill_stride,
                                                         unsigned long long* wave_log, float* __restrict__ image, uint8_t* __restrict__ code_out,
                                                         unsigned long long* __restrict__ rec_next, RenderConst rc) {
