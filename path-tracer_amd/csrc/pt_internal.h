@@ -11,6 +11,7 @@
                                      // in an HBM spill; the render's extend variants choose their own split (pt_kernels_extend.hip)
 #define PT_SCENE_LDS_QUADS 512       // a scene of at most this many 16-B quads (12 per object + 7 per triangle) is staged in LDS
 #define PT_STAGED_LDS_STACK 12       // LDS stack entries per ray of the staged extend variant
+#define PT_WIDE_LDS_STACK 14         // ... of the kind-scheduled wide walk: 14 + 5 parked words per lane = 4864 B per wave, 33 waves per CU's 160 KB (32 run)
 #define PT_TOP_LEVELS 7              // a mesh's tree-top block holds at most its first 7 levels (127 nodes, 8 KB); a scene uses as many
 #define PT_TOP_SLOTS 127             // levels as fit PT_SCENE_LDS_QUADS together with its TLAS and objects (pt_api.hip)
 #define PT_MAX_ITERS (1 << 20)       // traversal loop guard (degenerate N=1 trees can self-loop)

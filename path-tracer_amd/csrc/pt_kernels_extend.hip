@@ -45,20 +45,26 @@ struct Stack {
     }
     static constexpr int lds_n = LDS_N;
     static constexpr int block = BLOCK;
+    __device__ __forceinline__ int& park(int j) const { return lds[(LDS_N + j) * BLOCK]; }     // five words per lane behind the stack (tolerance-mode kernels only)
 };
 
+#define PT_ITER_OVERFLOW (1 << 30)
 struct Ray {
     f3 o, d, id;                 // origin, direction, 1/direction in the current space
     float hit_dist; int hit_obj, hit_tri;
     int sp, node, obj, switch_pt, iter;
-    int n_inner, n_leaf, n_enter, n_leave, overflow;
+    int n_inner, n_leaf, n_enter, n_leave;
+    // "stopped by a guard" is bit 30 of iter (one register less in every walk; iter itself stays below 2^21)
+    __device__ __forceinline__ void set_overflow(bool c) { iter |= c ? PT_ITER_OVERFLOW : 0; }
+    __device__ __forceinline__ int overflow() const { return (iter >> 30) & 1; }
+    __device__ __forceinline__ int trips() const { return iter & (PT_ITER_OVERFLOW - 1); }
 };
 
 __device__ __forceinline__ void ray_init(Ray& r, f3 o, f3 d, int root /* SceneView::tlas_root */) {
     r.o = o; r.d = d; r.id = rcp3(d);
     r.hit_dist = 1e6f; r.hit_obj = -1; r.hit_tri = -1;                       // scene.js:317-319
     r.sp = 0; r.node = root; r.obj = -1; r.switch_pt = -1; r.iter = 0;        // scene.js:321-324
-    r.n_inner = r.n_leaf = r.n_enter = r.n_leave = 0; r.overflow = 0;
+    r.n_inner = r.n_leaf = r.n_enter = r.n_leave = 0;
 }
 
 // scene.js:508-515 with 1/d hoisted (it only changes when the ray changes space)
@@ -111,7 +117,7 @@ __device__ __forceinline__ void near_first(float& ka, int& ra, float& kb, int& r
 template <bool COUNT, class STK, bool WIDE = false>
 __device__ __forceinline__ bool trav_step(const SceneView& sc, Ray& r, const STK& stk) {
     r.iter++;
-    if (!STK::shallow && r.iter > PT_MAX_ITERS) { r.overflow = 1; return false; }   // a scene with a stack bound has proper trees: the walk ends
+    if (!STK::shallow && r.iter > PT_MAX_ITERS) { r.set_overflow(true); return false; }   // a scene with a stack bound has proper trees: the walk ends
     if (r.sp < r.switch_pt) {                                   // :330-355 leaving the object
         const float4* ob = sc.objects + 8 * (int64_t)r.obj;
         switch_space(ob[0], ob[1], ob[2], r);
@@ -156,7 +162,7 @@ __device__ __forceinline__ bool trav_step(const SceneView& sc, Ray& r, const STK
         int nv = (k0 != INF) + (k1 != INF) + (k2 != INF) + (k3 != INF);
         if (nv == 0) { r.sp -= 1; r.node = stk.get(r.sp); }
         else {
-            if (r.sp + nv - 1 > PT_STACK_SIZE) { r.overflow = 1; return false; }
+            if (r.sp + nv - 1 > PT_STACK_SIZE) { r.set_overflow(true); return false; }
             if (nv > 3) { stk.put(r.sp, r3); r.sp += 1; }
             if (nv > 2) { stk.put(r.sp, r2); r.sp += 1; }
             if (nv > 1) { stk.put(r.sp, r1); r.sp += 1; }
@@ -175,7 +181,7 @@ __device__ __forceinline__ bool trav_step(const SceneView& sc, Ray& r, const STK
         const bool both = l_valid && r_valid;
         const bool take_l = l_valid && (!r_valid || l_dist < r_dist);
         if (both) {
-            if (!STK::shallow && __any(r.sp >= STK::lds_n) && r.sp >= PT_STACK_SIZE) { r.overflow = 1; return false; }
+            if (!STK::shallow && __any(r.sp >= STK::lds_n) && r.sp >= PT_STACK_SIZE) { r.set_overflow(true); return false; }
             stk.put(r.sp, take_l ? r_child : l_child);
             r.sp += 1;
         }
@@ -216,7 +222,7 @@ __device__ __forceinline__ int kind_after(const Ray& r) {
 template <class STK>
 __device__ __forceinline__ bool trip_guard(Ray& r) {
     r.iter++;
-    if (!STK::shallow && r.iter > PT_MAX_ITERS) { r.overflow = 1; return false; }
+    if (!STK::shallow && r.iter > PT_MAX_ITERS) { r.set_overflow(true); return false; }
     return true;
 }
 // TOP: the TLAS and the tree-top blocks of the meshes, node ids >= sc.n_tris, are in LDS at `lds` (staged by the kernel).
@@ -265,7 +271,7 @@ __device__ __forceinline__ int op_inner(const SceneView& sc, Ray& r, const STK& 
     // (push and pop without branches -- every lane writes its first free slot and reads its top entry whenever all of them are in
     // LDS -- was measured: -1 %, profiles/r02_instruction_cuts.txt)
     if (!(l_valid || r_valid)) { r.sp -= 1; r.node = stk.get(r.sp); }
-    if (!STK::shallow) r.overflow |= (stop || full) ? 1 : 0;
+    if (!STK::shallow) r.set_overflow(stop || full);
     return (stop || full) ? PT_K_DONE : kind_after<WIDE>(r);
 }
 // Tolerance mode: one 64-B record holds up to four quantised child boxes (pt_internal.h).  The nearest valid child is taken, the others
@@ -320,26 +326,32 @@ __device__ __forceinline__ int op_wide(const SceneView& sc, Ray& r, const STK& s
     r.sp = full ? r.sp : top;
     r.node = r0;
     if (k0 == INF) { r.sp -= 1; r.node = stk.get(r.sp); }
-    if (!STK::shallow) r.overflow |= (stop || full) ? 1 : 0;
+    if (!STK::shallow) r.set_overflow(stop || full);
     return (stop || full) ? PT_K_DONE : kind_after<true>(r);
 }
+// WIDE: the kind-scheduled wide walk keeps what only the triangle and switch bodies touch -- the direction, hit_obj, hit_tri -- in five
+// LDS words per lane behind the stack ("parked", Stack::park): the 4-wide node body is the one that needs the registers.
 template <bool COUNT, class STK, bool WIDE = false>
 __device__ __forceinline__ int op_leaf(const SceneView& sc, Ray& r, const STK& stk) {       // :380-391
     r.iter++;
     const bool stop = !STK::shallow && r.iter > PT_MAX_ITERS;                // as in op_inner: one exit; a stopped lane's test changes nothing
     int t = -(r.node + 1);
     const float4* tr = rec32<3>(sc.tris, t);
-    float dist = tri_hit(r.o, r.d, tr[0], tr[1], tr[2]);
-    if (!stop && dist > 0.0f && dist < r.hit_dist) { r.hit_dist = dist; r.hit_tri = t; r.hit_obj = r.obj; }
+    const f3 d = WIDE ? F3(__int_as_float(stk.park(0)), __int_as_float(stk.park(1)), __int_as_float(stk.park(2))) : r.d;
+    float dist = tri_hit(r.o, d, tr[0], tr[1], tr[2]);
+    if (!stop && dist > 0.0f && dist < r.hit_dist) {
+        r.hit_dist = dist;
+        if (WIDE) { stk.park(3) = r.obj; stk.park(4) = t; } else { r.hit_tri = t; r.hit_obj = r.obj; }
+    }
     if (COUNT) r.n_leaf += stop ? 0 : 1;
     r.sp -= 1; r.node = stk.get(r.sp);
-    if (!STK::shallow) r.overflow |= stop ? 1 : 0;
+    if (!STK::shallow) r.set_overflow(stop);
     return stop ? PT_K_DONE : kind_after<WIDE>(r);
 }
 // leaving (:330-355, rows 0-2 of the object = localToWorld) and entering (:357-379, rows 4-6 = worldToLocal, row 3 = root and
 // material) run the same arithmetic on different rows: one body serves both groups of lanes
 template <bool COUNT, class STK, bool WIDE = false>
-__device__ __forceinline__ int op_switch(const SceneView& sc, Ray& r) {
+__device__ __forceinline__ int op_switch(const SceneView& sc, Ray& r, const STK& stk) {
     const bool entering = r.obj < 0;
     if (entering && !trip_guard<STK>(r)) return PT_K_DONE;
     const int oi = entering ? -(r.node + 1) : r.obj;
@@ -347,7 +359,9 @@ __device__ __forceinline__ int op_switch(const SceneView& sc, Ray& r) {
     float4 r0 = ob[0], r1 = ob[1], r2 = ob[2];
     if (entering) { r.node = __float_as_int(ob[-1].x); r.switch_pt = r.sp; r.obj = oi; if (COUNT) r.n_enter++; }
     else { r.switch_pt = -1; r.obj = -1; if (COUNT) r.n_leave++; }
+    if (WIDE) r.d = F3(__int_as_float(stk.park(0)), __int_as_float(stk.park(1)), __int_as_float(stk.park(2)));
     switch_space(r0, r1, r2, r);
+    if (WIDE) { stk.park(0) = __float_as_int(r.d.x); stk.park(1) = __float_as_int(r.d.y); stk.park(2) = __float_as_int(r.d.z); }
     return kind_after<WIDE>(r);
 }
 // Runs the walk of every lane of the wave to its end.  `kind`: PT_K_INNER for a lane with a ray, PT_K_DONE for one without.
@@ -373,7 +387,7 @@ __device__ __forceinline__ void traverse_scheduled(const SceneView& sc, Ray& r, 
         } else if (cl >= cs) {
             do { if (kind == PT_K_LEAF) kind = op_leaf<COUNT, STK>(sc, r, stk); count(); if (COUNT) np_l++; } while (cl != 0 && ci < cl && cl >= cs);
         } else {
-            if (kind == PT_K_SWITCH) kind = op_switch<COUNT, STK>(sc, r);
+            if (kind == PT_K_SWITCH) kind = op_switch<COUNT, STK>(sc, r, stk);
             count(); if (COUNT) np_s++;
         }
     }
@@ -386,6 +400,7 @@ __device__ __forceinline__ void traverse_scheduled(const SceneView& sc, Ray& r, 
 template <bool COUNT, class STK>
 __device__ __forceinline__ void traverse_scheduled_wide(const SceneView& sc, Ray& r, const STK& stk, int kind, StepHeader* hdr = nullptr) {
     int ci, cw, cl, cs, np_i = 0, np_w = 0, np_l = 0, np_s = 0;
+    stk.park(0) = __float_as_int(r.d.x); stk.park(1) = __float_as_int(r.d.y); stk.park(2) = __float_as_int(r.d.z); stk.park(3) = r.hit_obj; stk.park(4) = r.hit_tri;
     auto count = [&]() {
         ci = __popcll(__ballot(kind == PT_K_INNER)) * sc.sched_wi; cw = __popcll(__ballot(kind == PT_K_WIDE)) * sc.sched_ww;
         cl = __popcll(__ballot(kind == PT_K_LEAF)) * sc.sched_wl; cs = __popcll(__ballot(kind == PT_K_SWITCH)) * sc.sched_ws;
@@ -400,10 +415,11 @@ __device__ __forceinline__ void traverse_scheduled_wide(const SceneView& sc, Ray
             if (kind == PT_K_INNER) kind = op_inner<COUNT, STK, false, true>(sc, r, stk);
             count(); if (COUNT) np_i++;
         } else {
-            if (kind == PT_K_SWITCH) kind = op_switch<COUNT, STK, true>(sc, r);
+            if (kind == PT_K_SWITCH) kind = op_switch<COUNT, STK, true>(sc, r, stk);
             count(); if (COUNT) np_s++;
         }
     }
+    r.d = F3(__int_as_float(stk.park(0)), __int_as_float(stk.park(1)), __int_as_float(stk.park(2))); r.hit_obj = stk.park(3); r.hit_tri = stk.park(4);
     if (COUNT && hdr && lane_id() == 0) {
         atomicAdd(&hdr->passes[0], (unsigned long long)np_i); atomicAdd(&hdr->passes[1], (unsigned long long)np_w);
         atomicAdd(&hdr->passes[2], (unsigned long long)np_l); atomicAdd(&hdr->passes[3], (unsigned long long)np_s);
@@ -467,7 +483,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96))) void k_
                                                         unsigned long long* wave_log, float* __restrict__ image, uint8_t* __restrict__ code_out,
                                                         unsigned long long* __restrict__ rec_next, RenderConst rc) {
     unsigned long long t_start = LOG ? wall_clock64() : 0;
-    __shared__ int s_stack[LDS_N * BLOCK];
+    __shared__ int s_stack[(LDS_N + ((WIDE && SCHED) ? 5 : 0)) * BLOCK];     // + the wide walk's parked words (op_leaf)
     int n_cam = hdr->n_camera, n_rays = n_cam + hdr->n_material;
     // ORDER 2: a launch lasts as long as its longest wave plus the time that wave waited to start
     // (profiles/r01_wave_timeline_*), so the class of rays that held the longest wave in the previous step is dispatched
@@ -505,7 +521,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96))) void k_
             if (m_lost) atomicAdd(&hdr->chk_lost, (unsigned long long)__popcll(m_lost));
             if (__float_as_uint(rel) > hdr->chk_max_rel_bits) atomicMax(&hdr->chk_max_rel_bits, __float_as_uint(rel));
         }
-        publish<false>(e.overflow, 0, 0, 0, 0, hdr);
+        publish<false>(e.overflow(), 0, 0, 0, 0, hdr);
         return;
     }
     const int bx = (int)blockIdx.x - (CHECK ? rc.chk_cap : 0);
@@ -578,9 +594,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96))) void k_
             todo &= ~m;
         }
     }
-    publish<COUNT>(r.overflow, r.n_inner, r.n_leaf, r.n_enter, r.n_leave, hdr);
+    publish<COUNT>(r.overflow(), r.n_inner, r.n_leaf, r.n_enter, r.n_leave, hdr);
     if (LOG) {
-        int trips = r.iter;
+        int trips = r.trips();
         for (int off = 32; off > 0; off >>= 1) trips = max(trips, __shfl_xor(trips, off));
         if (lane_id() == 0) {
             unsigned long long* w = wave_log + 4 * (int64_t)(blockIdx.x * (BLOCK >> 6) + (threadIdx.x >> 6));
@@ -590,7 +606,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96))) void k_
         }
     }
     if (ORDER == 2 && blockIdx.x % 5 == 0) {     // one workgroup in five (all XCDs) reports its waves' trip counts
-        int trips = r.iter;
+        int trips = r.trips();
         for (int off = 32; off > 0; off >>= 1) trips = max(trips, __shfl_xor(trips, off));
         if (lane_id() == 0) {
             unsigned* cell = &hdr->cls_max[(blockIdx.x / 5 * (BLOCK >> 6) + (threadIdx.x >> 6)) & 31][q < n_cam ? 0 : 1];
@@ -622,7 +638,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_extend_direct(SceneView sc, const 
         if (hit_dist) hit_dist[q] = r.hit_dist;
         if (counts4) counts4[q] = make_int4(r.n_inner, r.n_leaf, r.n_enter, r.n_leave);
     }
-    publish<false>(r.overflow, 0, 0, 0, 0, hdr);
+    publish<false>(r.overflow(), 0, 0, 0, 0, hdr);
 }
 
 // ---- launchers -------------------------------------------------------------------------------
@@ -678,8 +694,8 @@ void ptk_extend_queue(const PathState& ps, const RenderConst& rc, const SceneVie
     if (sc.wide && variant == 2)                                                                                                                                         // tolerance mode, per-lane loop (A/B)
         launch_queue<16, 64, 2, true>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
     else if (sc.wide && rc.check_period > 0)                                                                                                                             // tolerance mode, kind-scheduled, sampled exact re-walk
-        launch_queue<16, 64, 2, true, 0, false, true, 0, true>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
-    else if (sc.wide)      launch_queue<16, 64, 2, true, 0, false, true>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
+        launch_queue<PT_WIDE_LDS_STACK, 64, 2, true, 0, false, true, 0, true>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
+    else if (sc.wide)      launch_queue<PT_WIDE_LDS_STACK, 64, 2, true, 0, false, true>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
     else if (variant == 0) launch_queue<24, 256, 1>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
     else if (variant == 1) launch_queue<16, 64, 1>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
     else if (variant >= 3 && 12 * (int64_t)sc.n_objects + 7 * (int64_t)sc.n_tris <= PT_SCENE_LDS_QUADS) {
