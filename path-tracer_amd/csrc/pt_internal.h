@@ -91,6 +91,7 @@ struct StepHeader {
     unsigned long long visits[64][4];   // n_inner, n_leaf, n_enter, n_leave (counting variant only), spread over 64 slots
                                         // so that one word does not serialise every wave's atomic; summed by the host
     unsigned long long passes[4];       // counting variant only: passes of the kind-scheduled loop by body -- inner node, 4-wide node, triangle, switch -- summed over the waves
+    unsigned long long lane_hist[4];    // counting variant only: node-body passes (inner or wide) by active lanes: <= 16, <= 32, <= 48, <= 64
     int32_t  step_index, pad;
     // Dispatch order of the extend kernel (performance only, results do not depend on it): sampled waves report their trip
     // count (the longest lane's) per ray class, the scan of the next step puts the class that held the longest wave first.

@@ -6,7 +6,7 @@
 // All of it is HBM-streaming integer/f32 work; no LDS tiling or MFMA applies.  The refit is the
 // only inter-workgroup hand-off: device-scope atomics on both sides of one arrival counter.
 #include "pt_internal.h"
-#include "pt_math.cuh"
+#include "pt_math.h"
 
 static inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + PT_BLOCK - 1) / PT_BLOCK)); }
 

@@ -9,7 +9,7 @@
 // Stack: the first LDS_N entries of a lane's stack live in LDS as [entry][thread] (bank = thread & 31
 // whatever the entry, lanes l / l+32 are served in different LDS cycles: divergent depths never
 // conflict); deeper entries go to an HBM spill laid out [entry][slot] so that equal depths coalesce.
-#include "pt_shading.cuh"
+#include "pt_shading.h"
 #include <algorithm>
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
@@ -368,6 +368,7 @@ __device__ __forceinline__ int op_switch(const SceneView& sc, Ray& r, const STK&
 template <bool COUNT, class STK, int TOP = 0>
 __device__ __forceinline__ void traverse_scheduled(const SceneView& sc, Ray& r, const STK& stk, int kind, LdsQuads lds = nullptr, StepHeader* hdr = nullptr) {
     int np_i = 0, np_l = 0, np_s = 0;      // COUNT: passes by body (measurement: lane use = lane visits / (64 x passes))
+    int lh[4] = {0, 0, 0, 0};              // COUNT: node-body passes by active lanes
     // Same sequence of passes as "count, choose, run one body" in one loop; written as a tight loop per body inside the outer loop so
     // that a run of passes of one kind keeps the values that body does not touch where they are (no copies at the joins).
     int ci, cl, cs;
@@ -383,7 +384,8 @@ __device__ __forceinline__ void traverse_scheduled(const SceneView& sc, Ray& r, 
     count();
     while ((ci | cl | cs) != 0) {
         if (ci >= cl && ci >= cs) {
-            do { if (kind == PT_K_INNER) kind = op_inner<COUNT, STK, TOP>(sc, r, stk, lds); count(); if (COUNT) np_i++; } while (ci != 0 && ci >= cl && ci >= cs);
+            do { if (COUNT) lh[(__popcll(__ballot(kind == PT_K_INNER)) - 1) >> 4]++;
+                 if (kind == PT_K_INNER) kind = op_inner<COUNT, STK, TOP>(sc, r, stk, lds); count(); if (COUNT) np_i++; } while (ci != 0 && ci >= cl && ci >= cs);
         } else if (cl >= cs) {
             do { if (kind == PT_K_LEAF) kind = op_leaf<COUNT, STK>(sc, r, stk); count(); if (COUNT) np_l++; } while (cl != 0 && ci < cl && cl >= cs);
         } else {
@@ -393,13 +395,14 @@ __device__ __forceinline__ void traverse_scheduled(const SceneView& sc, Ray& r, 
     }
     if (COUNT && hdr && lane_id() == 0) {
         atomicAdd(&hdr->passes[0], (unsigned long long)np_i); atomicAdd(&hdr->passes[2], (unsigned long long)np_l); atomicAdd(&hdr->passes[3], (unsigned long long)np_s);
+        for (int k = 0; k < 4; k++) atomicAdd(&hdr->lane_hist[k], (unsigned long long)lh[k]);
     }
 }
 
 // The same for the tolerance mode: four bodies (binary TLAS node, 4-wide BLAS node, triangle, object switch).
 template <bool COUNT, class STK>
 __device__ __forceinline__ void traverse_scheduled_wide(const SceneView& sc, Ray& r, const STK& stk, int kind, StepHeader* hdr = nullptr) {
-    int ci, cw, cl, cs, np_i = 0, np_w = 0, np_l = 0, np_s = 0;
+    int ci, cw, cl, cs, np_i = 0, np_w = 0, np_l = 0, np_s = 0, lh[4] = {0, 0, 0, 0};
     stk.park(0) = __float_as_int(r.d.x); stk.park(1) = __float_as_int(r.d.y); stk.park(2) = __float_as_int(r.d.z); stk.park(3) = r.hit_obj; stk.park(4) = r.hit_tri;
     auto count = [&]() {
         ci = __popcll(__ballot(kind == PT_K_INNER)) * sc.sched_wi; cw = __popcll(__ballot(kind == PT_K_WIDE)) * sc.sched_ww;
@@ -408,7 +411,8 @@ __device__ __forceinline__ void traverse_scheduled_wide(const SceneView& sc, Ray
     count();
     while ((ci | cw | cl | cs) != 0) {
         if (cw >= ci && cw >= cl && cw >= cs) {
-            do { if (kind == PT_K_WIDE) kind = op_wide<COUNT, STK>(sc, r, stk); count(); if (COUNT) np_w++; } while (cw != 0 && cw >= ci && cw >= cl && cw >= cs);
+            do { if (COUNT) lh[(__popcll(__ballot(kind == PT_K_WIDE)) - 1) >> 4]++;
+                 if (kind == PT_K_WIDE) kind = op_wide<COUNT, STK>(sc, r, stk); count(); if (COUNT) np_w++; } while (cw != 0 && cw >= ci && cw >= cl && cw >= cs);
         } else if (cl >= ci && cl >= cs) {
             do { if (kind == PT_K_LEAF) kind = op_leaf<COUNT, STK, true>(sc, r, stk); count(); if (COUNT) np_l++; } while (cl != 0 && cw < cl && cl >= ci && cl >= cs);
         } else if (ci >= cs) {
@@ -423,6 +427,7 @@ __device__ __forceinline__ void traverse_scheduled_wide(const SceneView& sc, Ray
     if (COUNT && hdr && lane_id() == 0) {
         atomicAdd(&hdr->passes[0], (unsigned long long)np_i); atomicAdd(&hdr->passes[1], (unsigned long long)np_w);
         atomicAdd(&hdr->passes[2], (unsigned long long)np_l); atomicAdd(&hdr->passes[3], (unsigned long long)np_s);
+        for (int k = 0; k < 4; k++) atomicAdd(&hdr->lane_hist[k], (unsigned long long)lh[k]);
     }
 }
 

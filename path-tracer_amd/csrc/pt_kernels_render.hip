@@ -12,7 +12,7 @@
 // logic.js:158,168,205,213).  Because every camera-queue and every material-queue entry produces exactly one
 // ray, the ray-trace queue (QueuesStage3.ray_trace_queue) is the concatenation camera ++ material and is
 // never stored.
-#include "pt_shading.cuh"
+#include "pt_shading.h"
 
 static inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + PT_BLOCK - 1) / PT_BLOCK)); }
 

@@ -1,4 +1,4 @@
-// pt_math.cuh -- device-side arithmetic for the gfx950 kernels.
+// pt_math.h -- device-side arithmetic for the gfx950 kernels.
 //
 // The kernels compute in strict IEEE-754 binary32: this translation unit is compiled with
 // -ffp-contract=off (no FMA contraction) and correctly rounded divide/sqrt, and every

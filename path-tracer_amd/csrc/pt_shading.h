@@ -1,9 +1,9 @@
-// pt_shading.cuh -- the per-slot bodies of the logic, camera and material kernels (logic.js:62-152, camera.js:60-118,
+// pt_shading.h -- the per-slot bodies of the logic, camera and material kernels (logic.js:62-152, camera.js:60-118,
 // material.js:75-120).  Each only reads and writes its own slot's PathState (plus the image), which is what lets the
 // launches in pt_kernels_render.hip / pt_kernels_extend.hip call them from whichever thread holds the slot.
 #pragma once
 #include "pt_internal.h"
-#include "pt_math.cuh"
+#include "pt_math.h"
 
 #define ALBEDO0_POW 0.217637640824031f   // pow(0.5, 2.2): material.js:107 through :72
 #define ALBEDO1_POW 0.0289911870530680f  // pow(0.2, 2.2): material.js:110 through :72

@@ -26,13 +26,15 @@ scene = pta.scenes.populate(pta.init_scene(dev), desc); scene.build()
 pt = pta.init_path_tracer({"device": dev, "scene": scene, "image": {"width": w, "height": h}, "camera": desc["camera"],
                            "settings": dict({"samples": args.spp, "numPaths": args.paths}, **desc.get("settings", {}))})
 rs = pt.run(count_bytes=True)
-out = (C.c_int64 * 8)()
+out = (C.c_int64 * 12)()
 dev.call("pt_extend_pass_counts", out)
-p_i, p_w, p_l, p_s, v_n, v_l, v_e, v_x = list(out)
+p_i, p_w, p_l, p_s, v_n, v_l, v_e, v_x = list(out)[:8]
+hist = list(out)[8:]
 waves = rs.total_rays / 64
 print(f"# {args.config}{' tolerance mode' if args.fast else ''}: {rs.total_rays} rays in {rs.steps} steps, 1 pool of {args.paths}")
 print(f"lane visits per ray: nodes {v_n / rs.total_rays:.2f}  triangles {v_l / rs.total_rays:.2f}  enter {v_e / rs.total_rays:.3f}  leave {v_x / rs.total_rays:.3f}")
 print(f"passes per wave:     inner {p_i / waves:.1f}  wide {p_w / waves:.1f}  triangle {p_l / waves:.1f}  switch {p_s / waves:.1f}")
 node_p = p_i + p_w
 print(f"lane use: node bodies {v_n / (64 * max(node_p, 1)):.3f}   triangle body {v_l / (64 * max(p_l, 1)):.3f}   switch body {(v_e + v_x) / (64 * max(p_s, 1)):.3f}")
+print("node-body passes by lanes served (<=16, <=32, <=48, <=64):", [round(x / max(sum(hist), 1), 3) for x in hist])
 dev.destroy()
