@@ -12,7 +12,7 @@
 #include <string>
 #include <vector>
 
-// accessors of pt_ctx that pt_api.hip provides (the struct is private to that file)
+// accessors of pt_ctx that pt_api.hip provides (this file stays clear of pt_ctx.h)
 int pt_ctx_device(const pt_ctx* c);
 hipStream_t pt_ctx_stream(const pt_ctx* c);
 int pt_ctx_fail(pt_ctx* c, int code, const std::string& msg);

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_compact_generate_shade(PathState p
     // record, the shortest launch while the pool is full (6 waves per SIMD, one body per thread); PL = 4: one workgroup per
     // record, a quarter of the workgroups and of the prefix work -- half the cost of a step that has little else to do
     // (8 instead of 15 us for an empty pool, 24 instead of 34 us at 12 % live slots), slower with the pool full (48
-    // against 44.5 us: 5 waves per SIMD, four bodies in a row per thread).  The host picks (pt_api.hip enqueue_step).
+    // against 44.5 us: 5 waves per SIMD, four bodies in a row per thread).  The host picks (pt_api_render.hip enqueue_step).
     constexpr int NW = PT_BLOCK / 64, PER = PT_STEP_BLOCK / (PL * PT_BLOCK);
     static_assert(PER * PL * PT_BLOCK == PT_STEP_BLOCK, "a count record is a whole number of workgroups");
     __shared__ int4 s_cnt[PL][NW], s_front[NW], s_all[NW];
