@@ -492,6 +492,56 @@ def test_tolerance_mode_render_counts_its_differing_rays(pta, orc, device, built
     np.testing.assert_allclose(img_e[..., :3], orr.image()[..., :3], rtol=1e-5, atol=1e-6)
 
 
+def test_tolerance_mode_deep_stack_spill_and_odd_meshes(pta):
+    """The wide walk pushes up to three entries per node, so its stack outgrows the 14 LDS entries sooner than the reference walk's:
+    150,000 nearly coincident triangles and rays that enter every box (nothing is pruned) drive it through the HBM spill, in the
+    per-lane loop (pt_trace_rays) and in the kind-scheduled render kernel with every ray re-walked exactly: no guard hit, no hit lost,
+    nothing beyond the tolerance.  Then one-triangle and two-triangle meshes (the degenerate N = 1 tree, wide nodes with one or two
+    children) among nine meshes: the same."""
+    rng = np.random.default_rng(21)
+    n = 150_000
+    base = np.array([[-1, -1, 0], [1, -1, 0], [0, 1, 0]], np.float32)
+    v = (base[None] + rng.uniform(-1e-3, 1e-3, (n, 3, 3)).astype(np.float32)).reshape(-1, 3)
+    v[:, 2] += np.repeat(np.linspace(0, 0.5, n, dtype=np.float32), 3)
+    deep = {"meshes": [pta.scenes.mesh_from_vertices(v, np.arange(3 * n).reshape(-1, 3))], "instances": [(0, [0, 0, 0], [0, 0, 0], [1, 1, 1], 0)],
+            "camera": {"position": [-0.8, 0.8, 3], "lookAt": [-0.8, 0.8001, 0], "fov": 0.5}}
+    one = "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3"
+    two = "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nf 1 2 3\nf 1 3 4"
+    meshes = [{"file": one}, {"file": two}] + [pta.scenes.random_soup(40 + 13 * k, 100 + k, extent=0.6, size=0.3) for k in range(7)]
+    odd = {"meshes": meshes, "instances": [(k, [1.5 * (k % 3) - 1.5, 1.5 * (k // 3) - 1.5, 0.2 * k], [0.1 * k, 0.2, 0.3 * k], [1, 1, 1], k % 2) for k in range(9)],
+           "camera": {"position": [0, -7, 3], "lookAt": [0, 0, 0.5], "fov": 25}}
+    for name, desc, w, h, spp, paths in (("deep", deep, 16, 16, 8, 256), ("odd", odd, 96, 64, 16, 5000)):
+        dev = pta.request_device(0)
+        try:
+            s = pta.scenes.populate(pta.init_scene(dev), desc); s.build()
+            if name == "deep":
+                k = 192
+                miss = np.concatenate([rng.uniform(-0.85, -0.75, (k, 1)), rng.uniform(0.75, 0.85, (k, 1)), np.full((k, 1), 3.0)], axis=1)
+                hit = np.concatenate([rng.uniform(-0.3, 0.3, (k, 2)), np.full((k, 1), 3.0)], axis=1)
+                ro = np.concatenate([miss, hit]).astype(np.float32); rd = np.tile(np.float32([0, 0, -1]), (2 * k, 1))
+            else:
+                cam = np.float32(desc["camera"]["position"])
+                rd = (np.float32(desc["camera"]["lookAt"]) - cam)[None] + rng.normal(size=(20000, 3)).astype(np.float32) * 2.0
+                rd /= np.linalg.norm(rd, axis=1, keepdims=True); ro = np.broadcast_to(cam, rd.shape).copy()
+            a = s.trace_rays(ro, rd, counts=True)
+            assert s.last_guard_hits == 0
+            dev.call("pt_set_traversal_mode", pta.capi.PT_TRAVERSAL_WIDE)
+            dev.call("pt_set_traversal_check", 1)
+            b = s.trace_rays(ro, rd, counts=True)
+            assert s.last_guard_hits == 0, name
+            np.testing.assert_array_equal(a[0] >= 0, b[0] >= 0, err_msg=name)
+            both = a[0] >= 0
+            assert (np.abs(a[2][both] - b[2][both]) <= 1e-6 * a[2][both]).all(), name
+            if name == "deep":
+                assert b[3][:192, 0].min() > 30_000            # the rays through the empty half still enter every wide node
+            pt = pta.init_path_tracer({"device": dev, "scene": s, "image": {"width": w, "height": h}, "camera": desc["camera"], "settings": {"samples": spp, "numPaths": paths}})
+            rs = pt.run()
+            assert rs.total_samples == w * h * spp and rs.stack_overflows == 0, name
+            assert rs.checked_rays == rs.total_rays > 0 and rs.lost_hit_rays == 0 and rs.beyond_tolerance_rays == 0, (name, rs.checked_rays, rs.total_rays, rs.lost_hit_rays, rs.beyond_tolerance_rays)
+        finally:
+            dev.destroy()
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
 def test_every_extend_variant_is_bit_exact(pta, orc, device, built, variant):
     """The extend kernel's variants (workgroup shape, LDS/HBM stack split, dispatch order, kind scheduling, tiny scene or the tree
