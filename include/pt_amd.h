@@ -80,8 +80,9 @@ int pt_get_objects(pt_ctx* ctx, pt_object* out, int64_t n);
 int pt_get_tlas_perm(pt_ctx* ctx, int32_t* out, int64_t n);
 int pt_get_mesh_perm(pt_ctx* ctx, int mesh, int32_t* out, int64_t n);
 /* Test hook, no reference counterpart: the most traversal-stack entries any ray can hold in the built scene (inner nodes
- * on the longest TLAS path + on the longest BLAS path), or INT32_MAX when it was not evaluated (it is only evaluated for
- * scenes small enough to be staged in LDS; the extend kernel then needs neither its stack spill nor its overflow guard). */
+ * on the longest TLAS path + on the longest BLAS path), or INT32_MAX when no bound exists: a scene with a one-primitive tree (one
+ * instance, or a one-triangle mesh), whose right child is the node itself (SURVEY "Degenerate N=1"), or more than 2^20 objects.  Within
+ * the LDS share of a staged scene the extend kernel drops its spill path and its guards; within 64 the default kernel drops the guards. */
 int pt_scene_get_stack_bound(pt_ctx* ctx, int32_t* bound);
 
 /* Test hook over the extend kernel (ray-trace.js:53-69 + scene.js:313-475 intersect_bvh) for

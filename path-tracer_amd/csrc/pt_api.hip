@@ -43,8 +43,9 @@ int pt_fail(pt_ctx* c, int code, const std::string& msg) { if (c) c->err = msg; 
 
 // Most stack entries a ray can hold at once: every entry is the far child of an inner node on the path from the root to
 // the node being visited (TLAS part below switch_pt, BLAS part above it), so the bound is the number of inner nodes on the
-// longest root-to-leaf path of the TLAS plus that of the deepest BLAS.  Only evaluated (on the host, from the built nodes)
-// for scenes small enough for the LDS-staged extend variant, whose kernel then drops the spill path and the overflow guard.
+// longest root-to-leaf path of the TLAS plus that of the deepest BLAS.  The TLAS is walked on the host (up to 2^20 objects), a mesh's
+// longest path comes from the device (k_dfs_index, read back when the mesh is built).  A bound within the LDS share lets the staged
+// variant drop its spill path and its guards; a bound within PT_STACK_SIZE lets the default variant drop the guards (Stack GUARDED).
 // A tree the walk cannot finish on (the degenerate one-primitive tree can point at itself) leaves the bound unknown.
 static int tree_path_inner_nodes(const std::vector<pt_bvh_node>& nodes, int64_t first, int64_t count, int64_t root) {
     std::vector<std::pair<int64_t, int>> todo{{root, 1}};
@@ -60,13 +61,13 @@ static int tree_path_inner_nodes(const std::vector<pt_bvh_node>& nodes, int64_t 
 }
 static int scene_stack_bound(pt_ctx* c) {
     c->stack_bound = INT32_MAX;
-    if (12 * (int64_t)c->n_objects + 7 * c->n_tris > PT_SCENE_LDS_QUADS) return PT_OK;
-    std::vector<pt_bvh_node> tlas((size_t)c->n_objects), blas((size_t)c->n_tris); std::vector<pt_object> objs((size_t)c->n_objects);
+    if (c->n_objects > (1 << 20)) return PT_OK;
+    std::vector<pt_bvh_node> tlas((size_t)c->n_objects);
     int r;
-    if ((r = read_back(c, tlas.data(), c->d_tlas_nodes, tlas.size() * sizeof(pt_bvh_node))) || (r = read_back(c, blas.data(), c->d_blas_nodes, blas.size() * sizeof(pt_bvh_node))) ||
-        (r = read_back(c, objs.data(), c->d_objects, objs.size() * sizeof(pt_object)))) return r;
+    if ((r = read_back(c, tlas.data(), c->d_tlas_nodes, tlas.size() * sizeof(pt_bvh_node)))) return r;
     int64_t bound = tree_path_inner_nodes(tlas, 0, c->n_objects, 0), deepest = 0;
-    for (const pt_object& o : objs) deepest = std::max<int64_t>(deepest, tree_path_inner_nodes(blas, 0, c->n_tris, o.bvh_offset));
+    for (const Mesh& m : c->meshes)
+        if (m.used) deepest = std::max<int64_t>(deepest, m.n >= 2 ? m.max_inner_path : INT32_MAX);     // a one-triangle mesh is the degenerate tree
     c->stack_bound = (int32_t)std::min<int64_t>(bound + deepest, INT32_MAX);
     return PT_OK;
 }
@@ -151,7 +152,7 @@ int build_mesh(pt_ctx* c, Mesh& m) {
     if ((rc = build_bvh(c, d_aabb, d_keys, m.n, m.d_perm, m.d_nodes, m.d_dfs, m.d_depth))) return rc;
     ptk_rearrange(m.d_tris_in, m.d_perm, m.n, m.d_tris_sorted, c->stream);
     HIPOK(c, hipGetLastError());
-    HIPOK(c, hipStreamSynchronize(c->stream));
+    if ((rc = read_back(c, &m.max_inner_path, m.d_dfs + m.n + PT_TOP_SLOTS, 4))) return rc;     // k_dfs_index's maximum (the stream is synchronised by the copy)
     m.built = true;
     return PT_OK;
 }

@@ -21,6 +21,7 @@ struct Mesh {
     int32_t* d_dfs = nullptr;         // inner node -> its number in depth-first preorder (traversal-order copy of the BLAS);
                                       // behind these n entries: PT_TOP_SLOTS + 1 ints, the nodes of the first levels by heap slot (k_dfs_index)
     uint8_t* d_depth = nullptr;       // inner node -> links between it and the root (the even depths become the wide nodes of the tolerance mode)
+    int32_t max_inner_path = 0;       // inner nodes on the longest root-to-leaf path (k_dfs_index), 0 for a one-triangle mesh
     bool built = false, used = false; int64_t tri_offset = 0;
 };
 

@@ -223,6 +223,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_dfs_index(const int32_t* __restric
     }
     dfs[i] = first[i] + cnt;
     if (depth_out) depth_out[i] = (uint8_t)depth;            // <= 62 links (32 key bits + 30 index bits)
+    if (top_nodes) atomicMax(&top_nodes[PT_TOP_SLOTS], depth + 1);   // the spare cell behind the slots: inner nodes on the longest path from the root (preset to -1)
     if (top_nodes && depth > 0 && depth < PT_TOP_LEVELS) top_nodes[(1 << depth) - 1 + (int)path] = i;
 }
 // The tree-top block of one packed mesh: the nodes of its first `levels` levels, by heap slot, at node ids top_id .. of `trav`

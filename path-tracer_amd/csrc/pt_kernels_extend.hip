@@ -25,9 +25,13 @@ __device__ __forceinline__ int rank_below(unsigned long long mask) {
 
 // SHALLOW: the host has checked that no ray's stack can exceed LDS_N entries in this scene (TLAS depth + deepest BLAS
 // depth, pt_api.hip scene_stack_bound), so neither the spill nor the overflow guard is compiled in.
-template <int LDS_N, int BLOCK, bool SHALLOW = false>
+// GUARDED = false: the host knows a bound of at most PT_STACK_SIZE entries for this scene and that its trees are proper (no one-primitive
+// tree, whose right child is the node itself), so a walk ends by itself and never fills the stack: neither the iteration guard nor the
+// full-stack guard is compiled in (the spill stays).  SHALLOW implies it.
+template <int LDS_N, int BLOCK, bool SHALLOW = false, bool GUARDED = true>
 struct Stack {
     static constexpr bool shallow = SHALLOW;
+    static constexpr bool guarded = GUARDED && !SHALLOW;
     int* lds;            // &s_stack[0][thread]
     int32_t* spill_base; // &spill[0][0] (wave-uniform: the lane's address is only formed on the rare path that needs it)
     int slot;            // this lane's slot in a spill entry
@@ -117,7 +121,7 @@ __device__ __forceinline__ void near_first(float& ka, int& ra, float& kb, int& r
 template <bool COUNT, class STK, bool WIDE = false>
 __device__ __forceinline__ bool trav_step(const SceneView& sc, Ray& r, const STK& stk) {
     r.iter++;
-    if (!STK::shallow && r.iter > PT_MAX_ITERS) { r.set_overflow(true); return false; }   // a scene with a stack bound has proper trees: the walk ends
+    if (STK::guarded && r.iter > PT_MAX_ITERS) { r.set_overflow(true); return false; }   // a scene with a stack bound has proper trees: the walk ends
     if (r.sp < r.switch_pt) {                                   // :330-355 leaving the object
         const float4* ob = sc.objects + 8 * (int64_t)r.obj;
         switch_space(ob[0], ob[1], ob[2], r);
@@ -181,7 +185,7 @@ __device__ __forceinline__ bool trav_step(const SceneView& sc, Ray& r, const STK
         const bool both = l_valid && r_valid;
         const bool take_l = l_valid && (!r_valid || l_dist < r_dist);
         if (both) {
-            if (!STK::shallow && __any(r.sp >= STK::lds_n) && r.sp >= PT_STACK_SIZE) { r.set_overflow(true); return false; }
+            if (STK::guarded && __any(r.sp >= STK::lds_n) && r.sp >= PT_STACK_SIZE) { r.set_overflow(true); return false; }
             stk.put(r.sp, take_l ? r_child : l_child);
             r.sp += 1;
         }
@@ -222,7 +226,7 @@ __device__ __forceinline__ int kind_after(const Ray& r) {
 template <class STK>
 __device__ __forceinline__ bool trip_guard(Ray& r) {
     r.iter++;
-    if (!STK::shallow && r.iter > PT_MAX_ITERS) { r.set_overflow(true); return false; }
+    if (STK::guarded && r.iter > PT_MAX_ITERS) { r.set_overflow(true); return false; }
     return true;
 }
 // TOP: the TLAS and the tree-top blocks of the meshes, node ids >= sc.n_tris, are in LDS at `lds` (staged by the kernel).
@@ -237,7 +241,7 @@ __device__ __forceinline__ int op_inner(const SceneView& sc, Ray& r, const STK& 
     // One exit: a lane stopped by a guard runs the visit like the others (it changes no hit; its stack slot and node are its own and
     // never read again) and is retired at the end.  Early returns here cost every lane of every pass a dozen register copies.
     r.iter++;
-    const bool stop = !STK::shallow && r.iter > PT_MAX_ITERS;
+    const bool stop = STK::guarded && r.iter > PT_MAX_ITERS;
     float4 q0, q1, q2, q3;
     if (TOP == 1 && r.node >= sc.n_tris) {
         LdsQuads nd = lds + 4 * (r.node - sc.n_tris);
@@ -262,7 +266,7 @@ __device__ __forceinline__ int op_inner(const SceneView& sc, Ray& r, const STK& 
     int l_child = __float_as_int(q0.w), r_child = __float_as_int(q2.w);
     const bool both = l_valid && r_valid;
     const bool take_l = l_valid && (!r_valid || l_dist < r_dist);
-    const bool full = !STK::shallow && both && r.sp >= PT_STACK_SIZE;       // a push onto a full stack ends the ray
+    const bool full = STK::guarded && both && r.sp >= PT_STACK_SIZE;       // a push onto a full stack ends the ray
     if (both && !full) {
         stk.put(r.sp, take_l ? r_child : l_child);
         r.sp += 1;
@@ -271,7 +275,7 @@ __device__ __forceinline__ int op_inner(const SceneView& sc, Ray& r, const STK& 
     // (push and pop without branches -- every lane writes its first free slot and reads its top entry whenever all of them are in
     // LDS -- was measured: -1 %, profiles/r02_instruction_cuts.txt)
     if (!(l_valid || r_valid)) { r.sp -= 1; r.node = stk.get(r.sp); }
-    if (!STK::shallow) r.set_overflow(stop || full);
+    if (STK::guarded) r.set_overflow(stop || full);
     return (stop || full) ? PT_K_DONE : kind_after<WIDE>(r);
 }
 // Tolerance mode: one 64-B record holds up to four quantised child boxes (pt_internal.h).  The nearest valid child is taken, the others
@@ -287,7 +291,7 @@ __device__ __forceinline__ float fmin3_(float a, float b, float c) { float r; as
 template <bool COUNT, class STK>
 __device__ __forceinline__ int op_wide(const SceneView& sc, Ray& r, const STK& stk) {
     r.iter++;
-    const bool stop = !STK::shallow && r.iter > PT_MAX_ITERS;
+    const bool stop = STK::guarded && r.iter > PT_MAX_ITERS;
     const float4* nd = rec32<PT_WIDE_QUADS>(sc.wide, r.node);
     const float4 h = nd[0], rf = nd[1], qa = nd[2], qb = nd[3];
     if (COUNT) r.n_inner += stop ? 0 : 1;                       // one 64-B record
@@ -312,7 +316,7 @@ __device__ __forceinline__ int op_wide(const SceneView& sc, Ray& r, const STK& s
     // child j lands j entries below the new top of the stack
     const bool p1 = k1 != INF, p2 = k2 != INF, p3 = k3 != INF;
     const int top = r.sp + (int)p1 + (int)p2 + (int)p3;
-    const bool full = !STK::shallow && top > PT_STACK_SIZE;                 // pushes onto a full stack end the ray
+    const bool full = STK::guarded && top > PT_STACK_SIZE;                 // pushes onto a full stack end the ray
     if (STK::shallow || !__any(top > STK::lds_n)) {                         // ONE wave-uniform test for the three pushes: all of them stay in LDS
         int* t = stk.lds + top * STK::block;
         if (p1) t[-1 * STK::block] = r1;
@@ -326,7 +330,7 @@ __device__ __forceinline__ int op_wide(const SceneView& sc, Ray& r, const STK& s
     r.sp = full ? r.sp : top;
     r.node = r0;
     if (k0 == INF) { r.sp -= 1; r.node = stk.get(r.sp); }
-    if (!STK::shallow) r.set_overflow(stop || full);
+    if (STK::guarded) r.set_overflow(stop || full);
     return (stop || full) ? PT_K_DONE : kind_after<true>(r);
 }
 // WIDE: the kind-scheduled wide walk keeps what only the triangle and switch bodies touch -- the direction, hit_obj, hit_tri -- in five
@@ -334,7 +338,7 @@ __device__ __forceinline__ int op_wide(const SceneView& sc, Ray& r, const STK& s
 template <bool COUNT, class STK, bool WIDE = false>
 __device__ __forceinline__ int op_leaf(const SceneView& sc, Ray& r, const STK& stk) {       // :380-391
     r.iter++;
-    const bool stop = !STK::shallow && r.iter > PT_MAX_ITERS;                // as in op_inner: one exit; a stopped lane's test changes nothing
+    const bool stop = STK::guarded && r.iter > PT_MAX_ITERS;                // as in op_inner: one exit; a stopped lane's test changes nothing
     int t = -(r.node + 1);
     const float4* tr = rec32<3>(sc.tris, t);
     const f3 d = WIDE ? F3(__int_as_float(stk.park(0)), __int_as_float(stk.park(1)), __int_as_float(stk.park(2))) : r.d;
@@ -345,7 +349,7 @@ __device__ __forceinline__ int op_leaf(const SceneView& sc, Ray& r, const STK& s
     }
     if (COUNT) r.n_leaf += stop ? 0 : 1;
     r.sp -= 1; r.node = stk.get(r.sp);
-    if (!STK::shallow) r.set_overflow(stop);
+    if (STK::guarded) r.set_overflow(stop);
     return stop ? PT_K_DONE : kind_after<WIDE>(r);
 }
 // leaving (:330-355, rows 0-2 of the object = localToWorld) and entering (:357-379, rows 4-6 = worldToLocal, row 3 = root and
@@ -482,7 +486,7 @@ __device__ __forceinline__ void publish(unsigned long long ov, unsigned long lon
 // (rc.chk_buf, two halves by step parity), and the NEXT step's launch starts with rc.chk_cap extra workgroups that take those rays,
 // walk them exactly and compare: they are dispatched first, last as long as an ordinary wave, and share nothing with the other
 // workgroups but the counters.  (pt_render_run always issues at least one step after the last one that traced a ray.)
-template <int LDS_N, int BLOCK, bool COUNT, int ORDER, bool LOG, bool LOGIC, bool WIDE = false, int SCENE_QUADS = 0, bool SHALLOW = false, bool SCHED = false, int TOP = 0, bool CHECK = false>
+template <int LDS_N, int BLOCK, bool COUNT, int ORDER, bool LOG, bool LOGIC, bool WIDE = false, int SCENE_QUADS = 0, bool SHALLOW = false, bool SCHED = false, int TOP = 0, bool CHECK = false, bool GUARDED = true>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96))) void k_extend_queue(PathState ps, SceneView sc, StepHeader* hdr, const int32_t* __restrict__ cam_q,
                                                         const int32_t* __restrict__ mat_q, int32_t* spill, int64_t spill_stride,
                                                         unsigned long long* wave_log, float* __restrict__ image, uint8_t* __restrict__ code_out,
@@ -493,7 +497,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96))) void k_
     // ORDER 2: a launch lasts as long as its longest wave plus the time that wave waited to start
     // (profiles/r01_wave_timeline_*), so the class of rays that held the longest wave in the previous step is dispatched
     // first: queue order when that was a camera wave, reversed when it was a bounce wave (workgroup 0 of the compaction launch decides).
-    typedef Stack<LDS_N, BLOCK, SHALLOW> STK;
+    typedef Stack<LDS_N, BLOCK, SHALLOW, GUARDED> STK;
     if (CHECK && (int)blockIdx.x < rc.chk_cap) {
         // ---- one of the workgroups in front of the launch: the reference walk of the rays the previous step set aside ----
         const int P = rc.check_period, s = hdr->step_index;      // the compaction launch has already counted this step: s >= 1
@@ -651,7 +655,7 @@ static int64_t pad_to(int64_t n, int64_t m) { return (n + m - 1) / m * m; }
 // The spill is sized for the smallest LDS share any variant uses (12 entries) and the largest slot count.
 size_t ptk_spill_ints(int64_t n_rays) { return (size_t)pad_to(n_rays, 256) * (PT_STACK_SIZE - PT_STAGED_LDS_STACK); }
 
-template <int LDS_N, int BLOCK, int ORDER, bool WIDE = false, int SCENE_QUADS = 0, bool SHALLOW = false, bool SCHED = false, int TOP = 0, bool CHECK = false>
+template <int LDS_N, int BLOCK, int ORDER, bool WIDE = false, int SCENE_QUADS = 0, bool SHALLOW = false, bool SCHED = false, int TOP = 0, bool CHECK = false, bool GUARDED = true>
 static void launch_queue(const PathState& ps, int num_paths, int grid_rays, SceneView sc, StepHeader* hdr, const int32_t* cam_q,
                          const int32_t* mat_q, int32_t* spill, int count, unsigned long long* wave_log, float* image, uint8_t* code,
                          unsigned long long* rec_next, const RenderConst& rc, hipStream_t s) {
@@ -661,7 +665,7 @@ static void launch_queue(const PathState& ps, int num_paths, int grid_rays, Scen
     dim3 grid((unsigned)((std::max(1, std::min(num_paths, grid_rays)) + BLOCK - 1) / BLOCK));
     const size_t scene_lds = TOP == 1 ? 16 * (size_t)(12 * sc.n_objects + 4 * sc.top_nodes) : SCENE_QUADS > 0 ? 16 * (size_t)(12 * sc.n_objects + 7 * sc.n_tris) : 0;
     if (TOP == 1) sc.objects = sc.objects_top;
-#define PT_LAUNCH(COUNT, LOG, LOGIC) hipLaunchKernelGGL((k_extend_queue<LDS_N, BLOCK, COUNT, ORDER, LOG, LOGIC, WIDE, SCENE_QUADS, SHALLOW, SCHED, TOP, CHECK && LOGIC && !(COUNT)>), \
+#define PT_LAUNCH(COUNT, LOG, LOGIC) hipLaunchKernelGGL((k_extend_queue<LDS_N, BLOCK, COUNT, ORDER, LOG, LOGIC, WIDE, SCENE_QUADS, SHALLOW, SCHED, TOP, CHECK && LOGIC && !(COUNT), GUARDED>), \
                                                        dim3(grid.x + ((CHECK && LOGIC && !(COUNT)) ? (unsigned)rc.chk_cap : 0u)), dim3(BLOCK), scene_lds, s, ps, sc, hdr, \
                                                        cam_q, mat_q, spill, stride, wave_log, image, code, rec_next, rc)
     if (wave_log)    PT_LAUNCH(false, true, false);    // measurement replays (code == null): traversal only, idempotent
@@ -718,6 +722,8 @@ void ptk_extend_queue(const PathState& ps, const RenderConst& rc, const SceneVie
         launch_queue<16, 64, 2, false, 0, false, true, 2>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
     else if (variant == 7) launch_queue<16, 64, 2, false, 0, false, true>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
     else if (variant >= 5) launch_queue<PT_STAGED_LDS_STACK, 256, 2, false, 0, false, true>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
+    else if (variant == 4 && sc.stack_bound <= PT_STACK_SIZE)     // proper trees and a bound within the stack: no guards in the walk
+        launch_queue<16, 64, 2, false, 0, false, true, 0, false, false>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
     else if (variant == 4) launch_queue<16, 64, 2, false, 0, false, true>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
     else                   launch_queue<16, 64, 2>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
 }
