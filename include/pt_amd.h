@@ -270,11 +270,11 @@ int pt_extend_replay(pt_ctx* ctx, int variant, int reps, double* avg_us);
  * block << 32 | class << 24 | trips (class 0 camera, 1 bounce).  out: cap_waves * 4 uint64.  tools/wave_timeline.py */
 int pt_extend_wave_log(pt_ctx* ctx, int variant, uint64_t* out, int64_t cap_waves, int64_t* n_waves);
 
-/* After a pt_render_run with PT_RUN_COUNT_BYTES: out8[0..3] = passes of the kind-scheduled traversal loop by body (binary inner node,
- * 4-wide node, triangle, object switch), summed over the waves; out8[4..7] = lane visits (n_inner -- 64-B node records of either kind --,
- * n_leaf, n_enter, n_leave); out8[8..11] = node-body passes (inner or 4-wide) by the lanes they served: <= 16, <= 32, <= 48, <= 64.
- * Lane use of a body = its lane visits / (64 x its passes).  out8 holds 12 entries. */
-int pt_extend_pass_counts(pt_ctx* ctx, int64_t* out8);
+/* After a pt_render_run with PT_RUN_COUNT_BYTES: out12[0..3] = passes of the kind-scheduled traversal loop by body (binary inner node,
+ * 4-wide node, triangle, object switch), summed over the waves; out12[4..7] = lane visits (n_inner -- 64-B node records of either kind --,
+ * n_leaf, n_enter, n_leave); out12[8..11] = node-body passes (inner or 4-wide) by the lanes they served: <= 16, <= 32, <= 48, <= 64.
+ * Lane use of a body = its lane visits / (64 x its passes).  out12 holds 12 entries. */
+int pt_extend_pass_counts(pt_ctx* ctx, int64_t* out12);
 
 /* ---- display (scripts/display) ---- */
 /* replaces: initDisplay().draw() fragment shader (display.js:98-113) + canvas unorm8 store.

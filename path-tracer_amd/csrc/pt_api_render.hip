@@ -399,12 +399,12 @@ int pt_extend_replay(pt_ctx* c, int variant, int reps, double* avg_us) {
     return PT_OK;
 }
 
-int pt_extend_pass_counts(pt_ctx* c, int64_t* out8 /* 12 entries */) {
-    if (!c || !out8) return fail(c, PT_ERR_ARG, "pt_extend_pass_counts: null argument");
+int pt_extend_pass_counts(pt_ctx* c, int64_t* out12) {
+    if (!c || !out12) return fail(c, PT_ERR_ARG, "pt_extend_pass_counts: null argument");
     if (!c->render_ready || !c->h_hdr) return fail(c, PT_ERR_STATE, "pt_extend_pass_counts: no render");
     const StepHeader& h = *c->h_hdr;
-    for (int k = 0; k < 4; k++) { out8[k] = (int64_t)h.passes[k]; out8[4 + k] = 0; for (int sl = 0; sl < 64; sl++) out8[4 + k] += (int64_t)h.visits[sl][k]; }
-    for (int k = 0; k < 4; k++) out8[8 + k] = (int64_t)h.lane_hist[k];
+    for (int k = 0; k < 4; k++) { out12[k] = (int64_t)h.passes[k]; out12[4 + k] = 0; for (int sl = 0; sl < 64; sl++) out12[4 + k] += (int64_t)h.visits[sl][k]; }
+    for (int k = 0; k < 4; k++) out12[8 + k] = (int64_t)h.lane_hist[k];
     return PT_OK;
 }
 
