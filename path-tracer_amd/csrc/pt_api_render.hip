@@ -30,8 +30,13 @@ void enqueue_step(pt_ctx* c, int count_visits, hipEvent_t ev0, hipEvent_t ev1) {
     // several pools run together (pt_render_run_many) always one: the other pools' launches hide this one's latencies,
     // so the shape that does less work wins (+2 %).
     int fat = c->overlapped || c->step < 6 || (c->known_rays >= 0 && 2 * c->known_rays < c->rc.num_paths);
-    static const int shape = getenv("PT_COMPACT_SHAPE") ? atoi(getenv("PT_COMPACT_SHAPE")) : 0;   // measurement: 1 = always four per record, 2 = always one
-    if (shape) fat = shape == 2;
+    // ... and in 128-thread workgroups, unless the extend kernel is the LDS-staged one with its 256-thread workgroups: a compaction workgroup
+    // then fits where two extend waves of a CU have retired instead of waiting for four (configs[2] +2.3 %, 10 M grid +1.4 %, instanced +0.6 %;
+    // the Cornell box, staged, -2 %: profiles/r03_bench_ab_compaction_shape.txt)
+    const bool staged = extend_variant_of(c) >= 3 && 12 * (int64_t)c->n_objects + 7 * c->n_tris <= PT_SCENE_LDS_QUADS;
+    if (c->overlapped && !staged) fat = 5;
+    static const int shape = getenv("PT_COMPACT_SHAPE") ? atoi(getenv("PT_COMPACT_SHAPE")) : 0;   // measurement: 1 = always four per record, 2 = always one (256 threads), 3 .. 7 = the shapes of ptk_count_compact_generate_shade
+    if (shape) fat = shape >= 3 ? shape : shape == 2;
     ptk_count_compact_generate_shade(c->ps, c->rc, sv, c->d_code, c->d_blk_counts, parity, c->d_hdr, c->d_cam_q, c->d_mat_q, fat, c->stream);
     if (ev0) (void)hipEventRecord(ev0, c->stream);
     ptk_extend_queue(c->ps, c->rc, sv, c->d_hdr, c->d_cam_q, c->d_mat_q, c->d_spill, count_visits, extend_variant_of(c), nullptr, c->d_image, c->d_code,

@@ -168,7 +168,8 @@ int  ptk_step_blocks(int num_paths);   // count records per step; the code array
 void ptk_first_logic(const PathState& ps, const RenderConst& rc, uint8_t* code, int4* blk_counts, hipStream_t s);   // before step 0 only
 // counts -> queues, tickets, camera rays, StepHeader.  parity = step & 1 (StepHeader::ticket_next)
 void ptk_count_compact_generate_shade(const PathState& ps, const RenderConst& rc, const SceneView& sc, const uint8_t* code, int4* blk_counts, int parity, StepHeader* hdr,
-                                int32_t* cam_q, int32_t* mat_q, int fat /* one workgroup per count record: for steps with few live slots */, hipStream_t s);
+                                int32_t* cam_q, int32_t* mat_q, int fat /* 0: four 256-thread workgroups per count record; 1: one (for steps with few live slots); 5: one of
+                                128 threads (pools that overlap); 3, 4, 6, 7: other shapes, A/B only */, hipStream_t s);
 // Extend over the step's ray queue (camera ++ material), followed per slot by the next step's logic and material sample
 // (code != null; they write the decision codes and count records the next ptk_count_compact_generate_shade reads).  code == null: traversal only.
 // count != 0 selects the visit-counting variant.

@@ -60,8 +60,8 @@ __device__ __forceinline__ int4 wave_sum4(int4 v) {
         v = add4(v, make_int4(__shfl_xor(v.x, off), __shfl_xor(v.y, off), __shfl_xor(v.z, off), __shfl_xor(v.w, off)));
     return v;
 }
-template <int PL>
-__global__ __launch_bounds__(PT_BLOCK) void k_compact_generate_shade(PathState ps, RenderConst rc, SceneView sc, const uint8_t* __restrict__ code_in,
+template <int PL, int BLK = PT_BLOCK>
+__global__ __launch_bounds__(BLK) void k_compact_generate_shade(PathState ps, RenderConst rc, SceneView sc, const uint8_t* __restrict__ code_in,
                                                                      unsigned long long* __restrict__ rec, int nrecords, int parity, StepHeader* hdr,
                                                                      int32_t* __restrict__ cam_q, int32_t* __restrict__ mat_q) {
     // A workgroup takes PL planes of 256 consecutive slots (plane-major = slot order).  PL = 1: four workgroups per count
@@ -69,15 +69,15 @@ __global__ __launch_bounds__(PT_BLOCK) void k_compact_generate_shade(PathState p
     // record, a quarter of the workgroups and of the prefix work -- half the cost of a step that has little else to do
     // (8 instead of 15 us for an empty pool, 24 instead of 34 us at 12 % live slots), slower with the pool full (48
     // against 44.5 us: 5 waves per SIMD, four bodies in a row per thread).  The host picks (pt_api_render.hip enqueue_step).
-    constexpr int NW = PT_BLOCK / 64, PER = PT_STEP_BLOCK / (PL * PT_BLOCK);
-    static_assert(PER * PL * PT_BLOCK == PT_STEP_BLOCK, "a count record is a whole number of workgroups");
+    constexpr int NW = BLK / 64, PER = PT_STEP_BLOCK / (PL * BLK);     // BLK: threads per workgroup (64 = one wave: A/B of a workgroup that fits wherever one extend wave retires)
+    static_assert(PER * PL * BLK == PT_STEP_BLOCK, "a count record is a whole number of workgroups");
     __shared__ int4 s_cnt[PL][NW], s_front[NW], s_all[NW];
-    __shared__ unsigned short s_todo[PL * PT_BLOCK];
-    const int b = blockIdx.x, base = b * PL * PT_BLOCK, group = b / PER, sub = b % PER, wave = threadIdx.x >> 6, lane = lane_id();
+    __shared__ unsigned short s_todo[PL * BLK];
+    const int b = blockIdx.x, base = b * PL * BLK, group = b / PER, sub = b % PER, wave = threadIdx.x >> 6, lane = lane_id();
     unsigned code[PL]; unsigned long long b_cam[PL], b_mat[PL], b_tix[PL];
 #pragma unroll
     for (int p = 0; p < PL; p++) {
-        int i = base + p * PT_BLOCK + (int)threadIdx.x;
+        int i = base + p * BLK + (int)threadIdx.x;
         code[p] = i < rc.num_paths ? code_in[i] : 0u;
     }
 #pragma unroll
@@ -89,13 +89,13 @@ __global__ __launch_bounds__(PT_BLOCK) void k_compact_generate_shade(PathState p
     {   // counts in front of this workgroup; workgroup 0 adds up all records for the header
         const int upto = b == 0 ? nrecords : group;
         int4 acc = make_int4(0, 0, 0, 0);
-        for (int j = threadIdx.x; j < upto; j += PT_BLOCK) {
+        for (int j = threadIdx.x; j < upto; j += BLK) {
             unsigned long long v = rec[2 * j + parity];
             acc = add4(acc, make_int4((int)(v & 0xffffu), (int)((v >> 16) & 0xffffu), (int)((v >> 32) & 0xffffu), (int)(v >> 48)));
         }
         if (sub == 0 && threadIdx.x == 0) rec[2 * group + (parity ^ 1)] = 0ull;       // filled by the extend launch that follows
         for (int k = 0; k < sub * PL; k++) {                    // the planes of this record in front of this workgroup
-            unsigned c = code_in[group * PT_STEP_BLOCK + k * PT_BLOCK + threadIdx.x];
+            unsigned c = code_in[group * PT_STEP_BLOCK + k * BLK + threadIdx.x];
             acc.x += c & 1u; acc.y += (c >> 1) & 1u; acc.z += (c >> 2) & 1u;
         }
         acc = wave_sum4(acc);
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_compact_generate_shade(PathState p
     // pixel ticket here: the camera ray itself is made by the extend kernel, which traces it at once.
 #pragma unroll
     for (int p = 0; p < PL; p++) {
-        const int i = base + p * PT_BLOCK + (int)threadIdx.x, j = p * PT_BLOCK + (int)threadIdx.x;
+        const int i = base + p * BLK + (int)threadIdx.x, j = p * BLK + (int)threadIdx.x;
         const int r_cam = rank_below(b_cam[p]), r_mat = rank_below(b_mat[p]);
         if (code[p] & 1u) cam_q[off.x + loc[p].x + r_cam] = i;
         if (code[p] & 2u) { mat_q[off.y + loc[p].y + r_mat] = i; s_todo[loc[p].y + r_mat] = (unsigned short)j; }
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_compact_generate_shade(PathState p
         int2 h = ps.hit[slot]; shade_one(ps, sc, slot, h.x, h.y);
     };
     if (PL == 1) { if ((int)threadIdx.x < tot.y) body((int)threadIdx.x); }                  // no loop: fewer registers, 6 waves per SIMD
-    else for (int t = threadIdx.x; t < tot.y; t += PT_BLOCK) body(t);
+    else for (int t = threadIdx.x; t < tot.y; t += BLK) body(t);
 }
 
 // Adds the unfinished tickets' partial sums to the image (and clears them) so that a host looking at the image in
@@ -204,7 +204,14 @@ void ptk_first_logic(const PathState& ps, const RenderConst& rc, uint8_t* code, 
 void ptk_count_compact_generate_shade(const PathState& ps, const RenderConst& rc, const SceneView& sc, const uint8_t* code, int4* blk_counts, int parity, StepHeader* hdr,
                                 int32_t* cam_q, int32_t* mat_q, int fat, hipStream_t s) {
     int nrecords = ptk_step_blocks(rc.num_paths);
-    if (fat) hipLaunchKernelGGL(k_compact_generate_shade<PT_STEP_BLOCK / PT_BLOCK>, dim3(nrecords), dim3(PT_BLOCK), 0, s, ps, rc, sc, code, (unsigned long long*)blk_counts, nrecords, parity, hdr, cam_q, mat_q);
+#define PT_COMPACT(PLN, BLKN) hipLaunchKernelGGL((k_compact_generate_shade<PLN, BLKN>), dim3((PT_STEP_BLOCK / ((PLN) * (BLKN))) * nrecords), dim3(BLKN), 0, s, ps, rc, sc, code, (unsigned long long*)blk_counts, nrecords, parity, hdr, cam_q, mat_q)
+    if (fat == 3) PT_COMPACT(4, 64);          // A/B shapes (PT_COMPACT_SHAPE): one-wave workgroups, four per record
+    else if (fat == 4) PT_COMPACT(16, 64);    // one wave per record
+    else if (fat == 5) PT_COMPACT(8, 128);    // two waves per record
+    else if (fat == 6) PT_COMPACT(2, 128);    // two-wave workgroups, four per record
+    else if (fat == 7) PT_COMPACT(8, 64);     // one-wave workgroups, two per record
+#undef PT_COMPACT
+    else if (fat) hipLaunchKernelGGL(k_compact_generate_shade<PT_STEP_BLOCK / PT_BLOCK>, dim3(nrecords), dim3(PT_BLOCK), 0, s, ps, rc, sc, code, (unsigned long long*)blk_counts, nrecords, parity, hdr, cam_q, mat_q);
     else hipLaunchKernelGGL(k_compact_generate_shade<1>, grid_for(rc.num_paths), dim3(PT_BLOCK), 0, s, ps, rc, sc, code, (unsigned long long*)blk_counts, nrecords, parity, hdr, cam_q, mat_q);
 }
 void ptk_flush_tickets(const PathState& ps, int num_paths, float* image, hipStream_t s) {
