@@ -23,6 +23,16 @@ import os
 import sys
 import time
 
+# before torch starts the HIP runtime: the hosts' default at 4K is four path pools, which need more than HIP's four hardware queues
+# (path-tracer_amd/__init__.py sets the same default, but bench.py initialises the GPU through torch before it imports the package)
+# The GPU boxes export HIP's own default of 4; the bench raises it to 8 (never lowers a larger value) and says so in the line.
+try:
+    _hwq = int(os.environ.get("GPU_MAX_HW_QUEUES", "0"))
+except ValueError:
+    _hwq = 0
+if _hwq < 8:
+    os.environ["GPU_MAX_HW_QUEUES"] = "8"
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -240,6 +250,7 @@ def main():
             # (logic.js:177-190); they are part of `value`'s ray count, as they are of the reference's ray-trace queue
             "wasted_rays_per_render_per_gpu": wasted // args.steps, "useful_Mrays_per_s": round((all_rays - all_wasted) / elapsed / 1e6, 3),
             "scene_build_s": round(build_s, 3),
+            "hip_hardware_queues": int(os.environ["GPU_MAX_HW_QUEUES"]),     # GPU_MAX_HW_QUEUES as this process set it (see the top of the file)
         }
         if ranks_report:
             out["multi_gpu"] = ranks_report

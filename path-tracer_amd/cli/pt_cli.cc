@@ -100,6 +100,7 @@ static int dump_host(const std::string& file, const std::string& trs) {
 #define CHECK(call) do { int rc_ = (call); if (rc_ < 0) { fprintf(stderr, "%s failed (%d): %s\n", #call, rc_, pt_last_error(ctx)); if (ctx) pt_destroy(ctx); return 1; } } while (0)
 
 int main(int argc, char** argv) {
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);      // before the HIP runtime starts: four path pools (the 4K default) need more than HIP's four hardware queues; a caller's value is kept
     std::vector<std::string> objs, insts; std::string cam, out; bool json = false;
     int width = 512, height = 512, samples = 16, paths = 0, device = 0, progress = 0, pools = 0, gpus = 1;
     pt_render_ext ext; memset(&ext, 0, sizeof ext); bool have_ext = false; int traversal = PT_TRAVERSAL_REFERENCE;
@@ -139,7 +140,12 @@ int main(int argc, char** argv) {
     }
     // neither --paths nor --pools: the measured-best shape for the frame (three pools of a quarter of its pixels each, 750,000 .. 2,000,000
     // slots); the reference's own shape is --paths 1000000 --pools 1 (path-tracer.js:4), 38 % slower on MI355X
-    if (paths <= 0 && pools <= 0) { pools = 3; paths = (int)std::min<long long>(2000000, std::max<long long>(750000, (long long)width * height / 4)); }
+    // at 4K, with at least 8 hardware queues (GPU_MAX_HW_QUEUES, set to 8 at the top of main unless the caller has set it), four pools of 1,500,000
+    if (paths <= 0 && pools <= 0) {
+        pools = 3; paths = (int)std::min<long long>(2000000, std::max<long long>(750000, (long long)width * height / 4));
+        const char* q = getenv("GPU_MAX_HW_QUEUES");
+        if (paths >= 1500000 && q && atoi(q) >= 8) { pools = 4; paths = paths / 4 * 3; }
+    }
     pools = std::max(1, pools);
     std::vector<std::string> texts;
     if (objs.empty()) { texts.push_back(FLOOR_OBJ); if (insts.empty()) insts.push_back("0,10,10,-1.3,0,0,0,5,5,5,0"); }   // main.js:33

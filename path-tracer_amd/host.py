@@ -452,12 +452,27 @@ class PooledPathTracer:
             pt.device.destroy()
 
 
+def hw_queues():
+    """Hardware queues HIP gives this process (GPU_MAX_HW_QUEUES, HIP's default 4).  Streams beyond that number share a queue and their
+    kernels serialise, so more than three pools only pay with more queues.  The package asks for 8 when the variable is unset
+    (path-tracer_amd/__init__.py; it has to be in the environment before the HIP runtime starts)."""
+    import os
+    try:
+        return max(1, int(os.environ.get("GPU_MAX_HW_QUEUES", "4")))
+    except ValueError:
+        return 4
+
+
 def default_pool_shape(width, height):
     """(pools, numPaths) the hosts use when the caller fixes neither: three pools of a quarter of the frame's pixels each, between 750,000
-    slots (the optimum at 1080p) and 2,000,000 (the optimum at 4K); profiles/r01_pool_size_sweep_v3.json,
+    slots (the optimum at 1080p) and 2,000,000 (4K); at 4K, with at least 8 hardware queues, four pools of 1,500,000 (+5...6 % on the 4K
+    configs; with HIP's default of 4 queues a fourth pool shares a queue and loses 6 %); profiles/r01_pool_size_sweep_v3.json,
     profiles/r03_pool_shape_and_weight_sweeps.txt.  The reference has one pool of 1,000,000 (path-tracer.js:4); the shape only changes
     which random stream renders which pixel ticket and when launches run (each pool is bit-identical to the oracle's run of its share)."""
-    return 3, int(min(2_000_000, max(750_000, width * height // 4)))
+    paths = int(min(2_000_000, max(750_000, width * height // 4)))
+    if paths >= 1_500_000 and hw_queues() >= 8:
+        return 4, paths * 3 // 4
+    return 3, paths
 
 
 def init_path_tracer(params):

@@ -148,7 +148,14 @@ function initScene(device) {
 // its pixels each, between 750,000 slots (1080p) and 2,000,000 (4K).  The reference's own shape, one pool of NUM_PATHS = 1,000,000
 // (path-tracer.js:4), costs 38 % of the throughput on MI355X; { numPaths: 1000000, pools: 1 } asks for it.  The shape only changes which
 // random stream renders which pixel ticket and when launches run.
-function defaultPoolShape(width, height) { return { pools: 3, numPaths: Math.min(2000000, Math.max(750000, Math.floor(width * height / 4))) } }
+// At 4K, with at least 8 hardware queues (GPU_MAX_HW_QUEUES; set to 8 below unless the caller has set it -- it is read when the HIP
+// runtime starts, i.e. at the first requestDevice), four pools of 1,500,000: streams beyond the queue count share a queue and serialise.
+if (process.env.GPU_MAX_HW_QUEUES === undefined) process.env.GPU_MAX_HW_QUEUES = "8"
+function defaultPoolShape(width, height) {
+    const numPaths = Math.min(2000000, Math.max(750000, Math.floor(width * height / 4)))
+    const queues = Math.max(1, parseInt(process.env.GPU_MAX_HW_QUEUES || "4", 10) || 4)
+    return (numPaths >= 1500000 && queues >= 8) ? { pools: 4, numPaths: Math.floor(numPaths * 3 / 4) } : { pools: 3, numPaths }
+}
 function initPathTracer(params) {
     let s = params.settings || {}
     if (s.numPaths === undefined && s.pools === undefined) { s = Object.assign({}, s, defaultPoolShape(params.image.width, params.image.height)); params = Object.assign({}, params, { settings: s }) }

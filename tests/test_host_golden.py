@@ -73,8 +73,18 @@ def test_render_ext_packing_against_hand_written_bytes(pta):
 
 def test_default_pool_shape(pta):
     """What the hosts use when the caller fixes neither numPaths nor pools (the measured optima, DESIGN.md "Pools"): three pools of a quarter
-    of the frame's pixels each, clamped to 750,000 .. 2,000,000 slots."""
-    assert pta.host.default_pool_shape(1920, 1080) == (3, 750_000)
-    assert pta.host.default_pool_shape(3840, 2160) == (3, 2_000_000)
-    assert pta.host.default_pool_shape(512, 512) == (3, 750_000)
-    assert pta.host.default_pool_shape(2560, 1440) == (3, 921_600)
+    of the frame's pixels each, clamped to 750,000 .. 2,000,000 slots; at 4K four pools of 1,500,000 when HIP has at least 8 hardware queues."""
+    import os
+    old = os.environ.get("GPU_MAX_HW_QUEUES")
+    try:
+        for queues, at_4k in (("4", (3, 2_000_000)), ("8", (4, 1_500_000)), ("16", (4, 1_500_000)), ("junk", (3, 2_000_000))):
+            os.environ["GPU_MAX_HW_QUEUES"] = queues        # four pools only where every pool's stream gets a hardware queue of its own
+            assert pta.host.default_pool_shape(1920, 1080) == (3, 750_000)
+            assert pta.host.default_pool_shape(3840, 2160) == at_4k
+            assert pta.host.default_pool_shape(512, 512) == (3, 750_000)
+            assert pta.host.default_pool_shape(2560, 1440) == (3, 921_600)
+    finally:
+        if old is None:
+            os.environ.pop("GPU_MAX_HW_QUEUES", None)
+        else:
+            os.environ["GPU_MAX_HW_QUEUES"] = old
