@@ -258,9 +258,6 @@ def main():
         if args.fast:
             out["tolerance_check"] = {"rays_rewalked_exactly": checked, "different_hit": mismatched, "hit_vs_miss": flipped, "beyond_1e-6": beyond, "of_those_reference_hit_lost": lost, "max_rel_hit_dist_diff": max_rel,
                                       "share_rewalked": round(checked / max(rays, 1), 5)}
-        if world == 1 and args.config in BOTH_MODES and not args.no_extras:
-            out["other_mode"] = other_mode_pass(pta, gpu, args, w, h, spp, img, args.fast)
-            out["tolerance_mode_full_check"] = full_check_pass(pta, gpu, args, w, h, spp)
         if not args.no_extras:
             out["roofline"] = roofline_block(pta, dev, scene, desc, args, w, h, spp, pt, elapsed / args.steps * 1e3)
             out["reference_pool_shape"] = reference_shape_pass(pta, dev, scene, desc, w, h, spp)
@@ -270,6 +267,11 @@ def main():
                 out["configs1_cornell_Mrays_per_s"] = out["also"]["cornell"]["Mrays_per_s"]
                 out["previous_rounds"] = {"BENCH_r01 (headline = configs[1] cornell)": 12904.9, "BENCH_r02 (headline = configs[2] sphere)": 6182.0,
                                           "note": "compare value with r02's and configs1_cornell_Mrays_per_s with r01's"}
+        if world == 1 and args.config in BOTH_MODES and not args.no_extras:
+            # last of the GPU passes, with the main tracer's pools gone: their streams would otherwise keep hardware queues the other mode's pools need
+            pt.destroy(); pt = None
+            out["other_mode"] = other_mode_pass(pta, gpu, args, w, h, spp, img, args.fast)
+            out["tolerance_mode_full_check"] = full_check_pass(pta, gpu, args, w, h, spp)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pta, desc, w, h, args.cpu_spp, args.paths)
         print(json.dumps(out), flush=True)
@@ -278,7 +280,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    pt.destroy()                 # pool contexts borrow dev's scene: they go first
+    if pt is not None:
+        pt.destroy()             # pool contexts borrow dev's scene: they go first
     dev.destroy()
 
 
