@@ -65,6 +65,8 @@ int write_header(pt_ctx* c) {
             c->chk_cap_alloc = rc.chk_cap;
         }
         rc.chk_buf = c->d_chk_buf; rc.chk_spill = c->d_chk_spill;
+        static const int xcd_chunk = getenv("PT_XCD_CHUNK") ? std::max(0, atoi(getenv("PT_XCD_CHUNK"))) : 0;     // measurement override
+        rc.xcd_chunk = xcd_chunk; rc.pad0 = 0;
     }
     StepHeader h; memset(&h, 0, sizeof h);
     h.first_empty_step = -1; h.pixel_counter = c->ticket_begin; h.ticket_next[0] = c->ticket_begin;

@@ -116,6 +116,7 @@ struct RenderConst {
     // tolerance mode: the rays of one queue block in check_period are walked a second time, exactly (0 = none, 1 = all), by chk_cap
     // workgroups in front of the next step's extend launch; chk_buf: 2 x chk_cap x 9 x 64 words (ray, hit of the wide walk), chk_spill: those
     // workgroups' share of the traversal-stack spill.  Fixed for a render (set when it starts).
+    int32_t xcd_chunk, pad0;     // > 0: the extend launch gives an XCD runs of xcd_chunk consecutive queue blocks (workgroup i runs on XCD i % 8), 0: block i to workgroup i
     int32_t check_period, chk_cap;
     float* chk_buf; int32_t* chk_spill;
 };

@@ -533,7 +533,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96))) void k_
         publish<false>(e.overflow(), 0, 0, 0, 0, hdr);
         return;
     }
-    const int bx = (int)blockIdx.x - (CHECK ? rc.chk_cap : 0);
+    int bx = (int)blockIdx.x - (CHECK ? rc.chk_cap : 0);
+    if (rc.xcd_chunk > 0) {
+        // The hardware hands workgroup i to XCD i % 8, each with an L2 of its own: with block i on workgroup i eight neighbouring blocks -- rays
+        // through neighbouring pixels, the same nodes -- run on eight XCDs and every L2 fetches those nodes for itself.  Here every group of
+        // 8 C workgroups gives each XCD C consecutive blocks instead (the launcher rounds the grid up to whole groups).
+        const int C = rc.xcd_chunk, G = 8 * C, g = bx / G, r = bx - g * G;
+        bx = g * G + (r & 7) * C + (r >> 3);
+    }
     int nblk = (n_rays + BLOCK - 1) / BLOCK;
     int blk = (ORDER == 2 && hdr->extend_order) ? nblk - 1 - bx : bx;
     if (blk < 0 || blk >= nblk) return;
@@ -663,6 +670,7 @@ static void launch_queue(const PathState& ps, int num_paths, int grid_rays, Scen
     // grid_rays: an upper bound of this step's queue length the host knows (the pool size until the tickets have run out; then
     // the last queue length it has seen: once no ticket is left, a step's rays are a subset of the step before's)
     dim3 grid((unsigned)((std::max(1, std::min(num_paths, grid_rays)) + BLOCK - 1) / BLOCK));
+    if (rc.xcd_chunk > 0) grid.x = (grid.x + 8 * rc.xcd_chunk - 1) / (8 * rc.xcd_chunk) * (8 * rc.xcd_chunk);     // whole groups (k_extend_queue's XCD mapping)
     const size_t scene_lds = TOP == 1 ? 16 * (size_t)(12 * sc.n_objects + 4 * sc.top_nodes) : SCENE_QUADS > 0 ? 16 * (size_t)(12 * sc.n_objects + 7 * sc.n_tris) : 0;
     if (TOP == 1) sc.objects = sc.objects_top;
 #define PT_LAUNCH(COUNT, LOG, LOGIC) hipLaunchKernelGGL((k_extend_queue<LDS_N, BLOCK, COUNT, ORDER, LOG, LOGIC, WIDE, SCENE_QUADS, SHALLOW, SCHED, TOP, CHECK && LOGIC && !(COUNT), GUARDED>), \
