@@ -210,6 +210,7 @@ void ptk_count_compact_generate_shade(const PathState& ps, const RenderConst& rc
     else if (fat == 5) PT_COMPACT(8, 128);    // two waves per record
     else if (fat == 6) PT_COMPACT(2, 128);    // two-wave workgroups, four per record
     else if (fat == 7) PT_COMPACT(8, 64);     // one-wave workgroups, two per record
+    else if (fat == 8) PT_COMPACT(4, 128);    // two-wave workgroups, two per record
 #undef PT_COMPACT
     else if (fat) hipLaunchKernelGGL(k_compact_generate_shade<PT_STEP_BLOCK / PT_BLOCK>, dim3(nrecords), dim3(PT_BLOCK), 0, s, ps, rc, sc, code, (unsigned long long*)blk_counts, nrecords, parity, hdr, cam_q, mat_q);
     else hipLaunchKernelGGL(k_compact_generate_shade<1>, grid_for(rc.num_paths), dim3(PT_BLOCK), 0, s, ps, rc, sc, code, (unsigned long long*)blk_counts, nrecords, parity, hdr, cam_q, mat_q);
