@@ -249,9 +249,10 @@ void pt_comm_destroy(pt_comm* comm);
  * longer bit-comparable with the oracle: sample counts stay exact, images agree statistically.  The differing rays are COUNTED: one
  * 64-ray block of every step's ray queue in `period` (pt_set_traversal_check; default 256, 1 = every ray, 0 = none; which blocks rotates
  * with the step) is walked a second time with the reference walk, by extra workgroups of the next step's launch, and pt_run_stats reports how many of those returned another (hit_obj, hit_tri) and the
- * largest relative hit_dist difference.  PT_TRAVERSAL_AUTO picks WIDE when the scene's binary nodes (64 B per packed triangle)
- * exceed 256 MB -- they then no longer live in the caches and the walk is bound by dependent fetches -- and REFERENCE otherwise;
- * pt_get_traversal_mode tells which walk the built scene uses.  The reference-exact buffers (pt_get_*) are unchanged; the collapse
+ * largest relative hit_dist difference.  PT_TRAVERSAL_AUTO picks WIDE when the scene has at least 2^18 packed triangles per object
+ * -- long walks inside few objects, where halving the dependent fetches pays (+15 ... +31 % on a one-mesh scene of 0.5 ... 10 M
+ * triangles) -- and REFERENCE otherwise (many objects or small meshes lose 2 ... 26 % to the decode); pt_get_traversal_mode tells
+ * which walk the built scene uses.  The reference-exact buffers (pt_get_*) are unchanged; the collapse
  * costs about 22 B per triangle of extra device memory.  Contexts made by pt_create_sharing_scene inherit mode and period. */
 enum { PT_TRAVERSAL_REFERENCE = 0, PT_TRAVERSAL_WIDE = 1, PT_TRAVERSAL_AUTO = 2 };
 int pt_set_traversal_mode(pt_ctx* ctx, int mode);

@@ -82,12 +82,13 @@ int extend_variant_of(const pt_ctx* c) {
     return fits_32bit_offsets(c) ? v : std::min(v, 2);
 }
 
-// PT_TRAVERSAL_AUTO: the wide walk pays where the binary nodes do not stay in the caches -- they are 64 B per triangle, and the chip
-// has 8 x 4 MB of L2 in front of a 256 MB memory-side cache (measured, profiles/r03_mode_crossover.txt: 32 MB of nodes, 100 instances of
-// 500 k triangles, lose 20 % to the decode; 640 MB, the 10 M-triangle grid, gain).
-constexpr int64_t PT_AUTO_WIDE_NODE_BYTES = 256ll << 20;
+// PT_TRAVERSAL_AUTO: the wide walk pays where a ray's walk inside an object is long -- it halves the dependent fetches of that walk and
+// costs a decode per visit plus a fourth body in the scheduled loop.  Measured (profiles/r03_mode_crossover.txt): the one-mesh displaced
+// grid gains at every size, +15 % at 500 k triangles (31 MB of binary nodes, cache-resident) to +31 % at 10 M; scenes of many objects
+// lose -- 100 instances of 500 k triangles -8 %, the 82 k-triangle mesh over the floor -2 %, the Cornell box (whose reference walk runs
+// out of LDS) -26 %.  The rule that separates them: at least 2^18 packed triangles per object.
 bool wide_wanted(const pt_ctx* c) {
-    return c->traversal_mode == PT_TRAVERSAL_WIDE || (c->traversal_mode == PT_TRAVERSAL_AUTO && c->n_tris * 64 > PT_AUTO_WIDE_NODE_BYTES);
+    return c->traversal_mode == PT_TRAVERSAL_WIDE || (c->traversal_mode == PT_TRAVERSAL_AUTO && c->n_tris >= ((int64_t)std::max(c->n_objects, 1) << 18));
 }
 bool wide_in_use(const pt_ctx* c) { return c->d_wide && wide_wanted(c); }
 

@@ -21,7 +21,7 @@ function addon() {
 // ---- requestAdapter()/requestDevice() (main.js:3-4) ------------------------------------------------------------
 // options.traversal (no reference counterpart; pt_amd.h "tolerance mode"): "reference" (default, the bit-exact walk of scene.js:313-475),
 // "tolerance" (the 4-wide collapse north_star's allowance admits; the differing rays are counted in run()'s stats) or "auto" (tolerance
-// where the binary nodes exceed 256 MB); options.checkPeriod: one 64-ray queue block in N is walked a second time exactly (default 256).
+// where the scene has at least 2^18 packed triangles per object); options.checkPeriod: one 64-ray queue block in N is walked a second time exactly (default 256).
 const TRAVERSAL = { reference: 0, tolerance: 1, auto: 2 }
 function requestDevice(deviceId = 0, options = {}) {
     const ctx = addon().create(deviceId)

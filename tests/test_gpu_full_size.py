@@ -188,7 +188,7 @@ def test_tolerance_mode_at_full_size_counts_every_differing_ray(pta, capsys, nam
             dev.call("pt_set_traversal_check", 1)
             s = pta.scenes.populate(pta.init_scene(dev), desc); s.build()
             used = C.c_int(-1); dev.call("pt_get_traversal_mode", C.byref(used))
-            assert used.value == (pta.capi.PT_TRAVERSAL_REFERENCE if mode == pta.capi.PT_TRAVERSAL_REFERENCE else pta.capi.PT_TRAVERSAL_WIDE)   # AUTO picks the wide walk for 640 MB of nodes
+            assert used.value == (pta.capi.PT_TRAVERSAL_REFERENCE if mode == pta.capi.PT_TRAVERSAL_REFERENCE else pta.capi.PT_TRAVERSAL_WIDE)   # AUTO picks the wide walk: 10 M triangles in one object
             pt = pta.init_path_tracer({"device": dev, "scene": s, "image": {"width": w, "height": h}, "camera": desc["camera"],
                                        "settings": dict({"samples": spp, "numPaths": paths, "pools": k_pools}, **desc.get("settings", {}))})
             rs = pt.run()
