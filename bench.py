@@ -32,6 +32,9 @@ except ValueError:
     _hwq = 0
 if _hwq < 8:
     os.environ["GPU_MAX_HW_QUEUES"] = "8"
+# N > 1: RCCL shares device memory between the ranks' processes; this pool's host driver only supports dmabuf IPC (the boxes export
+# this already; kept here so that an environment built by a launcher cannot lose it)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np
 
