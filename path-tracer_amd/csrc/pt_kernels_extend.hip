@@ -236,7 +236,8 @@ typedef const volatile __attribute__((address_space(3))) v4f* LdsQuads;   // typ
                                                                           // (the compiler otherwise merges them into flat loads through a select of addresses)
 // TOP == 2 (extend variant 7, an A/B of north_star's "structure-of-arrays node buffers"): the four quads of a node come from four arrays
 // (SceneView::soa: quad k of node i at soa[k * soa_stride + i]) instead of one 64-B record.
-template <bool COUNT, class STK, int TOP = 0, bool WIDE = false>
+// KIND = false (traverse_masked): the caller classifies the lanes itself; the body only reports a lane stopped by a guard (1) or not (0).
+template <bool COUNT, class STK, int TOP = 0, bool WIDE = false, bool KIND = true>
 __device__ __forceinline__ int op_inner(const SceneView& sc, Ray& r, const STK& stk, LdsQuads lds = nullptr) {      // :392-439
     // One exit: a lane stopped by a guard runs the visit like the others (it changes no hit; its stack slot and node are its own and
     // never read again) and is retired at the end.  Early returns here cost every lane of every pass a dozen register copies.
@@ -276,6 +277,7 @@ __device__ __forceinline__ int op_inner(const SceneView& sc, Ray& r, const STK& 
     // LDS -- was measured: -1 %, profiles/r02_instruction_cuts.txt)
     if (!(l_valid || r_valid)) { r.sp -= 1; r.node = stk.get(r.sp); }
     if (STK::guarded) r.set_overflow(stop || full);
+    if (!KIND) return (stop || full) ? 1 : 0;
     return (stop || full) ? PT_K_DONE : kind_after<WIDE>(r);
 }
 // Tolerance mode: one 64-B record holds up to four quantised child boxes (pt_internal.h).  The nearest valid child is taken, the others
@@ -335,7 +337,7 @@ __device__ __forceinline__ int op_wide(const SceneView& sc, Ray& r, const STK& s
 }
 // WIDE: the kind-scheduled wide walk keeps what only the triangle and switch bodies touch -- the direction, hit_obj, hit_tri -- in five
 // LDS words per lane behind the stack ("parked", Stack::park): the 4-wide node body is the one that needs the registers.
-template <bool COUNT, class STK, bool WIDE = false>
+template <bool COUNT, class STK, bool WIDE = false, bool KIND = true>
 __device__ __forceinline__ int op_leaf(const SceneView& sc, Ray& r, const STK& stk) {       // :380-391
     r.iter++;
     const bool stop = STK::guarded && r.iter > PT_MAX_ITERS;                // as in op_inner: one exit; a stopped lane's test changes nothing
@@ -350,14 +352,15 @@ __device__ __forceinline__ int op_leaf(const SceneView& sc, Ray& r, const STK& s
     if (COUNT) r.n_leaf += stop ? 0 : 1;
     r.sp -= 1; r.node = stk.get(r.sp);
     if (STK::guarded) r.set_overflow(stop);
+    if (!KIND) return stop ? 1 : 0;
     return stop ? PT_K_DONE : kind_after<WIDE>(r);
 }
 // leaving (:330-355, rows 0-2 of the object = localToWorld) and entering (:357-379, rows 4-6 = worldToLocal, row 3 = root and
 // material) run the same arithmetic on different rows: one body serves both groups of lanes
-template <bool COUNT, class STK, bool WIDE = false>
+template <bool COUNT, class STK, bool WIDE = false, bool KIND = true>
 __device__ __forceinline__ int op_switch(const SceneView& sc, Ray& r, const STK& stk) {
     const bool entering = r.obj < 0;
-    if (entering && !trip_guard<STK>(r)) return PT_K_DONE;
+    if (entering && !trip_guard<STK>(r)) return KIND ? PT_K_DONE : 1;
     const int oi = entering ? -(r.node + 1) : r.obj;
     const float4* ob = (WIDE ? sc.objects_wide : sc.objects) + 8 * (int64_t)oi + (entering ? 4 : 0);
     float4 r0 = ob[0], r1 = ob[1], r2 = ob[2];
@@ -366,6 +369,7 @@ __device__ __forceinline__ int op_switch(const SceneView& sc, Ray& r, const STK&
     if (WIDE) r.d = F3(__int_as_float(stk.park(0)), __int_as_float(stk.park(1)), __int_as_float(stk.park(2)));
     switch_space(r0, r1, r2, r);
     if (WIDE) { stk.park(0) = __float_as_int(r.d.x); stk.park(1) = __float_as_int(r.d.y); stk.park(2) = __float_as_int(r.d.z); }
+    if (!KIND) return 0;
     return kind_after<WIDE>(r);
 }
 // Runs the walk of every lane of the wave to its end.  `kind`: PT_K_INNER for a lane with a ray, PT_K_DONE for one without.
@@ -389,12 +393,68 @@ __device__ __forceinline__ void traverse_scheduled(const SceneView& sc, Ray& r, 
     while ((ci | cl | cs) != 0) {
         if (ci >= cl && ci >= cs) {
             do { if (COUNT) lh[(__popcll(__ballot(kind == PT_K_INNER)) - 1) >> 4]++;
-                 if (kind == PT_K_INNER) kind = op_inner<COUNT, STK, TOP>(sc, r, stk, lds); count(); if (COUNT) np_i++; } while (ci != 0 && ci >= cl && ci >= cs);
+                 if (kind == PT_K_INNER) kind = op_inner<COUNT, STK, TOP>(sc, r, stk, lds);
+                 count(); if (COUNT) np_i++; } while (ci != 0 && ci >= cl && ci >= cs);
         } else if (cl >= cs) {
             do { if (kind == PT_K_LEAF) kind = op_leaf<COUNT, STK>(sc, r, stk); count(); if (COUNT) np_l++; } while (cl != 0 && ci < cl && cl >= cs);
         } else {
             if (kind == PT_K_SWITCH) kind = op_switch<COUNT, STK>(sc, r, stk);
             count(); if (COUNT) np_s++;
+        }
+    }
+    if (COUNT && hdr && lane_id() == 0) {
+        atomicAdd(&hdr->passes[0], (unsigned long long)np_i); atomicAdd(&hdr->passes[2], (unsigned long long)np_l); atomicAdd(&hdr->passes[3], (unsigned long long)np_s);
+        for (int k = 0; k < 4; k++) atomicAdd(&hdr->lane_hist[k], (unsigned long long)lh[k]);
+    }
+}
+
+// The same schedule with the lanes' kinds kept as three wave-wide masks in scalar registers instead of a kind per lane (MASKS, extend
+// variant 8).  A pass of traverse_scheduled pays for its bookkeeping in vector instructions: kind_after (four compares, three selects),
+// count() (three compares of the kind) and the body's own `kind == K` test -- eleven of the inner body's ~75.  Here a body runs under its
+// mask directly (inverse ballot: the mask IS the exec mask), and after it three compares under the full exec mask -- node >= 0,
+// sp < switch_pt, sp < 0 -- give the ballots from which scalar and/or/andn2 re-sort the lanes that ran; "inside an object" is a fourth
+// mask that only the switch body changes.  Same passes in the same order, same arithmetic per lane: bit-exact with variant 4.
+// Measured slower (profiles/r03_extend_ab_kind_masks.txt: -2...-4 % on identical queues, -1.6 % in the configs[2] render): 8 vector
+// instructions fewer per pass, 19 scalar ones more, in a dependent chain on the unit a CU's four SIMDs share.  Kept as an A/B variant.
+template <bool COUNT, class STK>
+__device__ __forceinline__ void traverse_masked(const SceneView& sc, Ray& r, const STK& stk, bool has_ray, StepHeader* hdr = nullptr) {
+    typedef unsigned long long u64;
+    u64 mi = __ballot(has_ray), ml = 0, ms = 0, in_obj = 0;
+    int np_i = 0, np_l = 0, np_s = 0, lh[4] = {0, 0, 0, 0};
+    // the lanes of `ran` are re-sorted by where the body left them (kind_after's rules); `dead`: lanes a guard has stopped
+    auto resort = [&](u64 ran, u64 dead) {
+        const u64 b_node = __ballot(r.node >= 0), b_leave = __ballot(r.sp < r.switch_pt), b_done = __ballot(r.sp < 0) | dead;
+        const u64 live = ran & ~b_done;
+        const u64 sw = live & (b_leave | (~b_node & ~in_obj));          // :330 leave first; :357 a TLAS leaf enters an object
+        const u64 inner = live & ~sw & b_node;
+        mi = (mi & ~ran) | inner; ms = (ms & ~ran) | sw; ml = (ml & ~ran) | (live & ~sw & ~b_node);
+    };
+    for (;;) {
+        int ci = __popcll(mi) * sc.sched_wi, cl = __popcll(ml) * sc.sched_wl, cs = __popcll(ms) * sc.sched_ws;
+        if ((ci | cl | cs) == 0) break;
+        if (ci >= cl && ci >= cs) {
+            do {
+                if (COUNT) { lh[(__popcll(mi) - 1) >> 4]++; np_i++; }
+                const u64 ran = mi; int dead = 0;
+                if (__builtin_amdgcn_inverse_ballot_w64(ran)) dead = op_inner<COUNT, STK, 0, false, false>(sc, r, stk);
+                resort(ran, STK::guarded ? __ballot(dead != 0) : 0ull);
+                ci = __popcll(mi) * sc.sched_wi; cl = __popcll(ml) * sc.sched_wl; cs = __popcll(ms) * sc.sched_ws;
+            } while (ci != 0 && ci >= cl && ci >= cs);
+        } else if (cl >= cs) {
+            do {
+                if (COUNT) np_l++;
+                const u64 ran = ml; int dead = 0;
+                if (__builtin_amdgcn_inverse_ballot_w64(ran)) dead = op_leaf<COUNT, STK, false, false>(sc, r, stk);
+                resort(ran, STK::guarded ? __ballot(dead != 0) : 0ull);
+                ci = __popcll(mi) * sc.sched_wi; cl = __popcll(ml) * sc.sched_wl; cs = __popcll(ms) * sc.sched_ws;
+            } while (cl != 0 && ci < cl && cl >= cs);
+        } else {
+            if (COUNT) np_s++;
+            const u64 ran = ms; int dead = 0;
+            if (__builtin_amdgcn_inverse_ballot_w64(ran)) dead = op_switch<COUNT, STK, false, false>(sc, r, stk);
+            const u64 d = STK::guarded ? __ballot(dead != 0) : 0ull;
+            in_obj = (in_obj & ~ran) | (ran & ~in_obj & ~d);          // the lanes that entered are inside now, the ones that left are not (a stopped lane is never looked at again)
+            resort(ran, d);
         }
     }
     if (COUNT && hdr && lane_id() == 0) {
@@ -576,6 +636,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96))) void k_
         if (!SCHED) while (trav_step<COUNT, STK, WIDE>(sc, r, stk)) {}
     }
     if (SCHED && WIDE) traverse_scheduled_wide<COUNT, STK>(sc, r, stk, q < n_rays ? PT_K_INNER : PT_K_DONE, hdr);
+    else if (SCHED && TOP == 3) traverse_masked<COUNT, STK>(sc, r, stk, q < n_rays, hdr);                     // the kinds as wave-wide masks
     else if (SCHED) traverse_scheduled<COUNT, STK, TOP>(sc, r, stk, q < n_rays ? PT_K_INNER : PT_K_DONE, (LdsQuads)s_scene, hdr);     // the whole wave walks together
     if (q < n_rays) {
         trav_finish<COUNT>(sc, r);
@@ -702,9 +763,10 @@ static const char* kVariantNames[] = {"256-thread workgroups, 24 LDS stack entri
                                       "as 3, kind-scheduled: each pass of the loop the wave runs the one body (inner node, triangle, object switch) that advances most lanes",
                                       "as 4 with 256-thread workgroups and 12 LDS stack entries whatever the scene's size (the workgroup shape an LDS-staged tree top needs)",
                                       "as 5; the TLAS, the objects and the first levels of every mesh's tree are staged in LDS (scenes too large to stage whole)",
-                                      "as 4 with the walk's node records split into four arrays of quads (structure of arrays)"};
-int ptk_extend_num_variants() { return 8; }
-const char* ptk_extend_variant_name(int v) { return (v >= 0 && v < 8) ? kVariantNames[v] : "?"; }
+                                      "as 4 with the walk's node records split into four arrays of quads (structure of arrays)",
+                                      "as 4 with the lanes' kinds kept as wave-wide masks in scalar registers (a body runs under its mask; three compares re-sort the lanes)"};
+int ptk_extend_num_variants() { return 9; }
+const char* ptk_extend_variant_name(int v) { return (v >= 0 && v < 9) ? kVariantNames[v] : "?"; }
 void ptk_extend_queue(const PathState& ps, const RenderConst& rc, const SceneView& sc, StepHeader* hdr, const int32_t* cam_q,
                       const int32_t* mat_q, int32_t* spill, int count, int variant, unsigned long long* wave_log, float* image, uint8_t* code,
                       unsigned long long* rec_next, int grid_rays, hipStream_t s) {
@@ -726,6 +788,9 @@ void ptk_extend_queue(const PathState& ps, const RenderConst& rc, const SceneVie
     }
     else if (variant == 6 && sc.top_nodes > 0 && sc.objects_top && 12 * (int64_t)sc.n_objects + 4 * (int64_t)sc.top_nodes <= PT_SCENE_LDS_QUADS)
         launch_queue<PT_STAGED_LDS_STACK, 256, 2, false, PT_SCENE_LDS_QUADS, false, true, 1>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
+    else if (variant == 8 && sc.stack_bound <= PT_STACK_SIZE)
+        launch_queue<16, 64, 2, false, 0, false, true, 3, false, false>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
+    else if (variant == 8) launch_queue<16, 64, 2, false, 0, false, true, 3>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
     else if (variant == 7 && sc.soa)                                                                      // as 4, the node quads from four arrays
         launch_queue<16, 64, 2, false, 0, false, true, 2>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
     else if (variant == 7) launch_queue<16, 64, 2, false, 0, false, true>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
