@@ -276,16 +276,9 @@ __device__ __forceinline__ int op_inner(const SceneView& sc, Ray& r, const STK& 
     // (push and pop without branches -- every lane writes its first free slot and reads its top entry whenever all of them are in
     // LDS -- was measured: -1 %, profiles/r02_instruction_cuts.txt)
     if (!(l_valid || r_valid)) { r.sp -= 1; r.node = stk.get(r.sp); }
-    if (TOP == 4 && both && !full) {
-        // Prefetch (extend variant 9): the child that was pushed is fetched for certain -- a pushed entry is always popped and visited -- but
-        // only after the walk below the near child, and then the pop waits for it alone.  One dword of its record is requested now, by a load
-        // that writes LDS directly (no register, nothing reads the word): the line travels while the near child's record does.
-        const int far = take_l ? r_child : l_child;
-        const char* rec = far >= 0 ? (const char*)sc.nodes + (uint32_t)far * 64u : (const char*)sc.tris + (uint32_t)(-(far + 1)) * 48u;
-        if (far >= 0 || r.obj >= 0)
-            __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)rec,
-                                             (__attribute__((address_space(3))) void*)(stk.lds - lane_id() + STK::lds_n * STK::block), 4, 0, 0);
-    }
+    // (Prefetching the pushed child's record here -- one dword by a load that writes LDS directly, no register -- was built as variant 9
+    // at commit 701babf and measured 8-11 % slower: loads return in order, so the near child's record waits for the prefetched line.
+    // profiles/r03_extend_ab_prefetch_pushed_child.txt)
     if (STK::guarded) r.set_overflow(stop || full);
     if (!KIND) return (stop || full) ? 1 : 0;
     return (stop || full) ? PT_K_DONE : kind_after<WIDE>(r);
@@ -562,7 +555,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96))) void k_
                                                         unsigned long long* wave_log, float* __restrict__ image, uint8_t* __restrict__ code_out,
                                                         unsigned long long* __restrict__ rec_next, RenderConst rc) {
     unsigned long long t_start = LOG ? wall_clock64() : 0;
-    __shared__ int s_stack[(LDS_N + ((WIDE && SCHED) ? 5 : 0) + (TOP == 4 ? 1 : 0)) * BLOCK];     // + the wide walk's parked words (op_leaf); + the row the prefetches of variant 9 write
+    __shared__ int s_stack[(LDS_N + ((WIDE && SCHED) ? 5 : 0)) * BLOCK];     // + the wide walk's parked words (op_leaf)
     int n_cam = hdr->n_camera, n_rays = n_cam + hdr->n_material;
     // ORDER 2: a launch lasts as long as its longest wave plus the time that wave waited to start
     // (profiles/r01_wave_timeline_*), so the class of rays that held the longest wave in the previous step is dispatched
@@ -774,10 +767,9 @@ static const char* kVariantNames[] = {"256-thread workgroups, 24 LDS stack entri
                                       "as 4 with 256-thread workgroups and 12 LDS stack entries whatever the scene's size (the workgroup shape an LDS-staged tree top needs)",
                                       "as 5; the TLAS, the objects and the first levels of every mesh's tree are staged in LDS (scenes too large to stage whole)",
                                       "as 4 with the walk's node records split into four arrays of quads (structure of arrays)",
-                                      "as 4 with the lanes' kinds kept as wave-wide masks in scalar registers (a body runs under its mask; three compares re-sort the lanes)",
-                                      "as 4; the record of a child that is pushed is prefetched (one dword, by a load that writes LDS directly)"};
-int ptk_extend_num_variants() { return 10; }
-const char* ptk_extend_variant_name(int v) { return (v >= 0 && v < 10) ? kVariantNames[v] : "?"; }
+                                      "as 4 with the lanes' kinds kept as wave-wide masks in scalar registers (a body runs under its mask; three compares re-sort the lanes)"};
+int ptk_extend_num_variants() { return 9; }
+const char* ptk_extend_variant_name(int v) { return (v >= 0 && v < 9) ? kVariantNames[v] : "?"; }
 void ptk_extend_queue(const PathState& ps, const RenderConst& rc, const SceneView& sc, StepHeader* hdr, const int32_t* cam_q,
                       const int32_t* mat_q, int32_t* spill, int count, int variant, unsigned long long* wave_log, float* image, uint8_t* code,
                       unsigned long long* rec_next, int grid_rays, hipStream_t s) {
@@ -799,9 +791,6 @@ void ptk_extend_queue(const PathState& ps, const RenderConst& rc, const SceneVie
     }
     else if (variant == 6 && sc.top_nodes > 0 && sc.objects_top && 12 * (int64_t)sc.n_objects + 4 * (int64_t)sc.top_nodes <= PT_SCENE_LDS_QUADS)
         launch_queue<PT_STAGED_LDS_STACK, 256, 2, false, PT_SCENE_LDS_QUADS, false, true, 1>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
-    else if (variant == 9 && sc.stack_bound <= PT_STACK_SIZE)
-        launch_queue<16, 64, 2, false, 0, false, true, 4, false, false>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
-    else if (variant == 9) launch_queue<16, 64, 2, false, 0, false, true, 4>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
     else if (variant == 8 && sc.stack_bound <= PT_STACK_SIZE)
         launch_queue<16, 64, 2, false, 0, false, true, 3, false, false>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
     else if (variant == 8) launch_queue<16, 64, 2, false, 0, false, true, 3>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
