@@ -77,8 +77,11 @@ static int scene_stack_bound(pt_ctx* c) {
 // The kind-scheduled bodies address records through 32-bit byte offsets (pt_kernels_extend.hip rec32): scenes with 2^26 or more records in
 // one array (4 GB of nodes) take the per-lane loop of variant 2, which addresses with 64 bits.
 bool fits_32bit_offsets(const pt_ctx* c) { return c->n_tris + c->n_objects + c->top_nodes < (1ll << 26) && c->n_wide < (1ll << 26); }
+// The library's choice (extend_variant < 0): the kind-scheduled walk; with more than one object the one whose triangle passes also serve
+// the lanes at inner nodes (variant 9: +4 % on configs[2], +5 % on 100 instances, profiles/r03_extend_ab_fused_pass.txt; the one-object
+// grid loses 1 % with it and keeps variant 4).  A scene small enough for the LDS stage takes the staged kernel either way.
 int extend_variant_of(const pt_ctx* c) {
-    const int v = c->extend_variant >= 0 ? c->extend_variant : 4;
+    const int v = c->extend_variant >= 0 ? c->extend_variant : (c->n_objects > 1 ? 9 : 4);
     return fits_32bit_offsets(c) ? v : std::min(v, 2);
 }
 
@@ -100,6 +103,12 @@ SceneView scene_view(const pt_ctx* c) {
     v.n_objects = c->n_objects; v.n_tris = (int32_t)std::min<int64_t>(c->n_tris, INT32_MAX);
     v.tlas_root = v.n_tris;
     v.sched_wi = c->n_objects > 1 ? 6 : 3; v.sched_wl = 9; v.sched_ws = 5;                   // profiles/r02_sched_weight_sweep.txt
+    if (extend_variant_of(c) == 9 && !wide_in_use(c) && 12 * (int64_t)c->n_objects + 7 * c->n_tris > PT_SCENE_LDS_QUADS) {
+        // the fused pass makes a triangle pass cheap in trips to memory: it is worth running for fewer waiting lanes; a scene of many
+        // objects wants its switches sooner as well (profiles/r03_extend_ab_fused_pass.txt)
+        if (c->n_objects > 8) { v.sched_wi = 4; v.sched_wl = 12; v.sched_ws = 8; }
+        else                  { v.sched_wi = 6; v.sched_wl = 30; v.sched_ws = 5; }
+    }
     v.sched_ww = 3;                                                                          // profiles/r03_wide_weight_sweep.txt
     static const struct EnvWeights {                                                         // measurement override: PT_SCHED_W="inner,triangle,switch"
         int w[4] = {0, 0, 0, 0};
@@ -250,7 +259,7 @@ int pt_create(int device_id, pt_ctx** out) {
         return fail(nullptr, PT_ERR_HIP, std::string("pt_create: hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
     }
     c->own_stream = true;
-    c->extend_variant = -1;  // automatic: variant 4 (kind-scheduled walk)
+    c->extend_variant = -1;  // automatic: the kind-scheduled walk, variant 9 or 4 (extend_variant_of)
     if (const char* v = getenv("PT_EXTEND_VARIANT")) {       // measurement override; anything but a variant number is refused, not guessed at
         char* end = nullptr; long n = strtol(v, &end, 10);
         if (end == v || *end != 0 || n < -1 || n >= ptk_extend_num_variants()) {

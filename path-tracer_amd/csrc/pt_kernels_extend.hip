@@ -208,7 +208,8 @@ __device__ __forceinline__ bool trav_step(const SceneView& sc, Ray& r, const STK
 // triangles only) -- a model fed with the oracle's per-ray kind sequences had promised 1.4x fewer, by pricing the bodies too low.
 // What it does buy is fewer waits (SQ_WAIT_ANY -14 %): in the full render it was +3...8 % on scenes with several objects and -12 %
 // on the one-object grid with the first weights; with the inner body's weight per scene (SceneView::sched_wi: 3 for one object, 6
-// otherwise) it wins there too, and variant 4 is the library's default for every scene (pt_api.hip extend_variant_of).
+// otherwise) it wins there too: the kind-scheduled walk is the library's default for every scene (pt_api.hip extend_variant_of: variant 4,
+// or variant 9 -- the same with the fused inner + triangle pass below -- for scenes of more than one object).
 // --------------------------------------------------------------------------------------------
 // (The tolerance-mode kernels need 65-72 registers, 7 waves per SIMD.  Capped at 64 for 8 waves they spill two registers inside the
 // outer loop and lose 11 %: profiles/r03_wide_occupancy_ab.txt.)
@@ -293,6 +294,8 @@ __device__ __forceinline__ int op_inner(const SceneView& sc, Ray& r, const STK& 
 __device__ __forceinline__ float ubyte_f32(unsigned w, int c) { return (float)((w >> (8 * c)) & 0xffu); }     // v_cvt_f32_ubyte<c>
 __device__ __forceinline__ float fmax3_(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float fmin3_(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+// (The fused pass of op_inner_leaf -- this body also serving the lanes at a triangle -- was measured here too: 10 M grid -2.8 %, 100
+// instances +0.2 %, profiles/r03_extend_ab_fused_pass.txt; not kept.)
 template <bool COUNT, class STK>
 __device__ __forceinline__ int op_wide(const SceneView& sc, Ray& r, const STK& stk) {
     r.iter++;
@@ -375,6 +378,44 @@ __device__ __forceinline__ int op_switch(const SceneView& sc, Ray& r, const STK&
     if (!KIND) return 0;
     return kind_after<WIDE>(r);
 }
+// FUSED (extend variant 9): one pass for the lanes at an inner node AND the lanes at a triangle.  Both records are requested by the same
+// four load instructions (a lane's address is its node's or its triangle's; the fourth quad is only loaded for a node), then the two
+// groups run their arithmetic one after the other: the vector instructions of an inner pass plus a triangle pass, ONE trip to memory.
+// Run where the schedule chooses the triangle body while lanes wait at inner nodes: their visit would be the next pass anyway.
+// (Serving the lanes at an object switch too, in the passes that choose the switch body, was measured: it needs 66 registers -- forced
+// to 64 it spills outside the loop only -- and gives +0.7 % on 100 instances, -3 % on configs[2]: profiles/r03_extend_ab_fused_pass.txt.)
+template <bool COUNT, class STK>
+__device__ __forceinline__ int op_inner_leaf(const SceneView& sc, Ray& r, const STK& stk) {
+    r.iter++;
+    const bool stop = STK::guarded && r.iter > PT_MAX_ITERS;
+    const bool leaf = r.node < 0;
+    const int t = -(r.node + 1);
+    const char* rec_b = leaf ? (const char*)sc.tris + (uint32_t)t * 48u : (const char*)sc.nodes + (uint32_t)r.node * 64u;
+    const float4* rec = (const float4*)rec_b;
+    float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (!leaf) q3 = rec[3];
+    bool full = false;
+    if (leaf) {                                                                 // :380-391, as op_leaf
+        float dist = tri_hit(r.o, r.d, q0, q1, q2);
+        if (!stop && dist > 0.0f && dist < r.hit_dist) { r.hit_dist = dist; r.hit_tri = t; r.hit_obj = r.obj; }
+        if (COUNT) r.n_leaf += stop ? 0 : 1;
+        r.sp -= 1; r.node = stk.get(r.sp);
+    } else {                                                                    // :392-439, as op_inner
+        if (COUNT) r.n_inner += stop ? 0 : 1;
+        float l_dist = slab(F3(q0), F3(q1), r.o, r.id), r_dist = slab(F3(q2), F3(q3), r.o, r.id);
+        bool l_valid = l_dist != -1e30f && l_dist < r.hit_dist;
+        bool r_valid = r_dist != -1e30f && r_dist < r.hit_dist;
+        int l_child = __float_as_int(q0.w), r_child = __float_as_int(q2.w);
+        const bool both = l_valid && r_valid;
+        const bool take_l = l_valid && (!r_valid || l_dist < r_dist);
+        full = STK::guarded && both && r.sp >= PT_STACK_SIZE;
+        if (both && !full) { stk.put(r.sp, take_l ? r_child : l_child); r.sp += 1; }
+        r.node = take_l ? l_child : r_child;
+        if (!(l_valid || r_valid)) { r.sp -= 1; r.node = stk.get(r.sp); }
+    }
+    if (STK::guarded) r.set_overflow(stop || full);
+    return (stop || full) ? PT_K_DONE : kind_after<false>(r);
+}
 // Runs the walk of every lane of the wave to its end.  `kind`: PT_K_INNER for a lane with a ray, PT_K_DONE for one without.
 template <bool COUNT, class STK, int TOP = 0>
 __device__ __forceinline__ void traverse_scheduled(const SceneView& sc, Ray& r, const STK& stk, int kind, LdsQuads lds = nullptr, StepHeader* hdr = nullptr) {
@@ -399,7 +440,9 @@ __device__ __forceinline__ void traverse_scheduled(const SceneView& sc, Ray& r, 
                  if (kind == PT_K_INNER) kind = op_inner<COUNT, STK, TOP>(sc, r, stk, lds);
                  count(); if (COUNT) np_i++; } while (ci != 0 && ci >= cl && ci >= cs);
         } else if (cl >= cs) {
-            do { if (kind == PT_K_LEAF) kind = op_leaf<COUNT, STK>(sc, r, stk); count(); if (COUNT) np_l++; } while (cl != 0 && ci < cl && cl >= cs);
+            do { if (TOP == 4) { if (kind == PT_K_LEAF || kind == PT_K_INNER) kind = op_inner_leaf<COUNT, STK>(sc, r, stk); }
+                 else if (kind == PT_K_LEAF) kind = op_leaf<COUNT, STK>(sc, r, stk);
+                 count(); if (COUNT) np_l++; } while (cl != 0 && ci < cl && cl >= cs);
         } else {
             if (kind == PT_K_SWITCH) kind = op_switch<COUNT, STK>(sc, r, stk);
             count(); if (COUNT) np_s++;
@@ -767,9 +810,10 @@ static const char* kVariantNames[] = {"256-thread workgroups, 24 LDS stack entri
                                       "as 4 with 256-thread workgroups and 12 LDS stack entries whatever the scene's size (the workgroup shape an LDS-staged tree top needs)",
                                       "as 5; the TLAS, the objects and the first levels of every mesh's tree are staged in LDS (scenes too large to stage whole)",
                                       "as 4 with the walk's node records split into four arrays of quads (structure of arrays)",
-                                      "as 4 with the lanes' kinds kept as wave-wide masks in scalar registers (a body runs under its mask; three compares re-sort the lanes)"};
-int ptk_extend_num_variants() { return 9; }
-const char* ptk_extend_variant_name(int v) { return (v >= 0 && v < 9) ? kVariantNames[v] : "?"; }
+                                      "as 4 with the lanes' kinds kept as wave-wide masks in scalar registers (a body runs under its mask; three compares re-sort the lanes)",
+                                      "as 4; a triangle pass also serves the lanes at inner nodes (both records by the same loads: one trip to memory for the two bodies)"};
+int ptk_extend_num_variants() { return 10; }
+const char* ptk_extend_variant_name(int v) { return (v >= 0 && v < 10) ? kVariantNames[v] : "?"; }
 void ptk_extend_queue(const PathState& ps, const RenderConst& rc, const SceneView& sc, StepHeader* hdr, const int32_t* cam_q,
                       const int32_t* mat_q, int32_t* spill, int count, int variant, unsigned long long* wave_log, float* image, uint8_t* code,
                       unsigned long long* rec_next, int grid_rays, hipStream_t s) {
@@ -791,6 +835,9 @@ void ptk_extend_queue(const PathState& ps, const RenderConst& rc, const SceneVie
     }
     else if (variant == 6 && sc.top_nodes > 0 && sc.objects_top && 12 * (int64_t)sc.n_objects + 4 * (int64_t)sc.top_nodes <= PT_SCENE_LDS_QUADS)
         launch_queue<PT_STAGED_LDS_STACK, 256, 2, false, PT_SCENE_LDS_QUADS, false, true, 1>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
+    else if (variant == 9 && sc.stack_bound <= PT_STACK_SIZE)
+        launch_queue<16, 64, 2, false, 0, false, true, 4, false, false>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
+    else if (variant == 9) launch_queue<16, 64, 2, false, 0, false, true, 4>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
     else if (variant == 8 && sc.stack_bound <= PT_STACK_SIZE)
         launch_queue<16, 64, 2, false, 0, false, true, 3, false, false>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
     else if (variant == 8) launch_queue<16, 64, 2, false, 0, false, true, 3>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);

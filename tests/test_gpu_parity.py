@@ -542,14 +542,14 @@ def test_tolerance_mode_deep_stack_spill_and_odd_meshes(pta):
             dev.destroy()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
 def test_every_extend_variant_is_bit_exact(pta, orc, device, built, variant):
     """The extend kernel's variants (workgroup shape, LDS/HBM stack split, dispatch order, kind scheduling, tiny scene or the tree
     tops staged in LDS) never change a result: whole path state against the oracle after each of 8 steps, on a scene that fits
     the LDS stage whole, on one whose two meshes get 5-level top blocks and on one with three instances of two meshes."""
     import ctypes as C
     name = C.create_string_buffer(200)
-    assert device.lib.pt_extend_variants(device.ctx, variant, name, 200) == 9 and name.value
+    assert device.lib.pt_extend_variants(device.ctx, variant, name, 200) == 10 and name.value
     try:
         device.call("pt_set_extend_variant", variant)
         for scene_name, w, h, spp, paths in (("cornell", 64, 36, 8, 3000), ("sphere", 48, 32, 8, 2500), ("soup_ties", 48, 32, 8, 2500)):
