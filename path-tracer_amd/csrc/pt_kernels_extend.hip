@@ -235,6 +235,30 @@ __device__ __forceinline__ bool trip_guard(Ray& r) {
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef const volatile __attribute__((address_space(3))) v4f* LdsQuads;   // typed as LDS, and volatile, so that the two fetch paths below stay two
                                                                           // (the compiler otherwise merges them into flat loads through a select of addresses)
+// The visit of the inner node whose record is in q0..q3 (:392-439): both slab tests, the nearer valid child next, the other one pushed,
+// a pop when neither is valid.  Returns whether a push found the stack full (guarded stacks only).
+template <class STK>
+__device__ __forceinline__ bool inner_visit(Ray& r, const STK& stk, float4 q0, float4 q1, float4 q2, float4 q3) {
+    float l_dist = slab(F3(q0), F3(q1), r.o, r.id), r_dist = slab(F3(q2), F3(q3), r.o, r.id);
+    bool l_valid = l_dist != -1e30f && l_dist < r.hit_dist;
+    bool r_valid = r_dist != -1e30f && r_dist < r.hit_dist;
+    int l_child = __float_as_int(q0.w), r_child = __float_as_int(q2.w);
+    const bool both = l_valid && r_valid;
+    const bool take_l = l_valid && (!r_valid || l_dist < r_dist);
+    const bool full = STK::guarded && both && r.sp >= PT_STACK_SIZE;       // a push onto a full stack ends the ray
+    if (both && !full) {
+        stk.put(r.sp, take_l ? r_child : l_child);
+        r.sp += 1;
+    }
+    r.node = take_l ? l_child : r_child;
+    // (push and pop without branches -- every lane writes its first free slot and reads its top entry whenever all of them are in
+    // LDS -- was measured: -1 %, profiles/r02_instruction_cuts.txt)
+    if (!(l_valid || r_valid)) { r.sp -= 1; r.node = stk.get(r.sp); }
+    // (Prefetching the pushed child's record here -- one dword by a load that writes LDS directly, no register -- was built as an A/B
+    // variant at commit 701babf and measured 8-11 % slower: loads return in order, so the near child's record waits for the prefetched
+    // line.  profiles/r03_extend_ab_prefetch_pushed_child.txt)
+    return full;
+}
 // TOP == 2 (extend variant 7, an A/B of north_star's "structure-of-arrays node buffers"): the four quads of a node come from four arrays
 // (SceneView::soa: quad k of node i at soa[k * soa_stride + i]) instead of one 64-B record.
 // KIND = false (traverse_masked): the caller classifies the lanes itself; the body only reports a lane stopped by a guard (1) or not (0).
@@ -262,24 +286,7 @@ __device__ __forceinline__ int op_inner(const SceneView& sc, Ray& r, const STK& 
 #pragma unroll
       for (int i = 0; i < PT_EXTRA_VALU; i++) asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc) : "v"(q3.w)); }
 #endif
-    float l_dist = slab(F3(q0), F3(q1), r.o, r.id), r_dist = slab(F3(q2), F3(q3), r.o, r.id);
-    bool l_valid = l_dist != -1e30f && l_dist < r.hit_dist;
-    bool r_valid = r_dist != -1e30f && r_dist < r.hit_dist;
-    int l_child = __float_as_int(q0.w), r_child = __float_as_int(q2.w);
-    const bool both = l_valid && r_valid;
-    const bool take_l = l_valid && (!r_valid || l_dist < r_dist);
-    const bool full = STK::guarded && both && r.sp >= PT_STACK_SIZE;       // a push onto a full stack ends the ray
-    if (both && !full) {
-        stk.put(r.sp, take_l ? r_child : l_child);
-        r.sp += 1;
-    }
-    r.node = take_l ? l_child : r_child;
-    // (push and pop without branches -- every lane writes its first free slot and reads its top entry whenever all of them are in
-    // LDS -- was measured: -1 %, profiles/r02_instruction_cuts.txt)
-    if (!(l_valid || r_valid)) { r.sp -= 1; r.node = stk.get(r.sp); }
-    // (Prefetching the pushed child's record here -- one dword by a load that writes LDS directly, no register -- was built as variant 9
-    // at commit 701babf and measured 8-11 % slower: loads return in order, so the near child's record waits for the prefetched line.
-    // profiles/r03_extend_ab_prefetch_pushed_child.txt)
+    const bool full = inner_visit(r, stk, q0, q1, q2, q3);
     if (STK::guarded) r.set_overflow(stop || full);
     if (!KIND) return (stop || full) ? 1 : 0;
     return (stop || full) ? PT_K_DONE : kind_after<WIDE>(r);
@@ -402,16 +409,7 @@ __device__ __forceinline__ int op_inner_leaf(const SceneView& sc, Ray& r, const 
         r.sp -= 1; r.node = stk.get(r.sp);
     } else {                                                                    // :392-439, as op_inner
         if (COUNT) r.n_inner += stop ? 0 : 1;
-        float l_dist = slab(F3(q0), F3(q1), r.o, r.id), r_dist = slab(F3(q2), F3(q3), r.o, r.id);
-        bool l_valid = l_dist != -1e30f && l_dist < r.hit_dist;
-        bool r_valid = r_dist != -1e30f && r_dist < r.hit_dist;
-        int l_child = __float_as_int(q0.w), r_child = __float_as_int(q2.w);
-        const bool both = l_valid && r_valid;
-        const bool take_l = l_valid && (!r_valid || l_dist < r_dist);
-        full = STK::guarded && both && r.sp >= PT_STACK_SIZE;
-        if (both && !full) { stk.put(r.sp, take_l ? r_child : l_child); r.sp += 1; }
-        r.node = take_l ? l_child : r_child;
-        if (!(l_valid || r_valid)) { r.sp -= 1; r.node = stk.get(r.sp); }
+        full = inner_visit(r, stk, q0, q1, q2, q3);
     }
     if (STK::guarded) r.set_overflow(stop || full);
     return (stop || full) ? PT_K_DONE : kind_after<false>(r);
