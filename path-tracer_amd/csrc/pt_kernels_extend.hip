@@ -824,6 +824,7 @@ void ptk_extend_queue(const PathState& ps, const RenderConst& rc, const SceneVie
     else if (variant == 1) launch_queue<16, 64, 1>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
     else if (variant >= 3 && 12 * (int64_t)sc.n_objects + 7 * (int64_t)sc.n_tris <= PT_SCENE_LDS_QUADS) {
         if (sc.stack_bound <= PT_STAGED_LDS_STACK) {    // no ray's stack can leave LDS: no spill path, no overflow guard
+            // (the fused pass of variant 9 in this kernel -- trips to LDS, not to memory -- measured -2 % on the Cornell box: profiles/r03_extend_ab_fused_pass.txt)
             if (variant >= 4) launch_queue<PT_STAGED_LDS_STACK, 256, 2, false, PT_SCENE_LDS_QUADS, true, true>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
             else launch_queue<PT_STAGED_LDS_STACK, 256, 2, false, PT_SCENE_LDS_QUADS, true>(ps, rc.num_paths, grid_rays, sc, hdr, cam_q, mat_q, spill, count, wave_log, image, code, rec_next, rc, s);
         } else {
